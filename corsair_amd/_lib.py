@@ -1,0 +1,141 @@
+"""ctypes binding of libcorsair_hip.so (the C ABI declared in include/corsair_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a compute entry point is
+called without a HIP device, this module raises.  PyTorch is used only as the owner of device
+memory and streams (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcorsair_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "corsair_hip.h")
+
+_lib = None
+
+
+class CorsairHipError(RuntimeError):
+    """Raised when a cs_* entry point returns a negative status (message = cs_last_error())."""
+
+
+def _declare(lib):
+    vp = c_void_p
+    sigs = {
+        "cs_last_error": (c_char_p, []),
+        "cs_version": (c_int, []),
+        "cs_device_count": (c_int, []),
+        "cs_coordmap_create": (c_int, [vp, c_int64, c_int, vp, POINTER(vp)]),
+        "cs_coordmap_stride": (c_int, [vp, c_int, vp, POINTER(vp)]),
+        "cs_coordmap_size": (c_int64, [vp]),
+        "cs_coordmap_tensor_stride": (c_int, [vp]),
+        "cs_coordmap_coords": (vp, [vp]),
+        "cs_coordmap_free": (None, [vp]),
+        "cs_kernelmap_build": (c_int, [vp, vp, c_int, c_int, vp, POINTER(vp)]),
+        "cs_kernelmap_num_pairs": (c_int64, [vp]),
+        "cs_kernelmap_rows": (c_int64, [vp]),
+        "cs_kernelmap_table": (vp, [vp]),
+        "cs_kernelmap_export": (c_int64, [vp, vp, vp, vp, c_int64, vp]),
+        "cs_kernelmap_free": (None, [vp]),
+        "cs_conv_fwd": (c_int, [vp, c_int64, c_int64, vp, c_int, c_int, vp, c_int, vp, vp, vp,
+                                c_int, c_int, vp, c_int, vp]),
+        "cs_affine_act": (c_int, [c_int64, c_int, vp, c_int, vp, vp, vp, c_int, c_int, vp, c_int, vp]),
+        "cs_row_l2_normalize": (c_int, [c_int64, c_int, vp, c_int, c_float, vp, c_int, vp]),
+        "cs_segmented_max": (c_int, [c_int64, c_int, vp, c_int, vp, c_int, c_int, vp, vp]),
+        "cs_voxelize": (c_int, [vp, POINTER(c_int64), c_int, c_double, vp, vp, POINTER(c_int64), vp]),
+        "cs_l2_topk": (c_int, [vp, c_int64, vp, c_int64, c_int, c_int, vp, vp, vp]),
+        "cs_knn_feat": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), c_int, c_int, c_int,
+                                vp, vp, vp, vp, vp, vp]),
+        "cs_chamfer_1dir": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), POINTER(c_int32),
+                                    POINTER(c_int32), c_int, vp, vp, vp]),
+        "cs_ransac_batch": (c_int, [vp, vp, POINTER(c_int64), c_int, c_float, c_int, c_int, c_double,
+                                    c_uint64, vp, vp, vp, vp, vp]),
+        "cs_symcut_fit": (c_int, [vp, c_int, vp, POINTER(c_int64), c_int, vp, c_int,
+                                  POINTER(c_int32), c_int, c_int, c_int, c_uint64, vp, vp, vp, vp, vp]),
+        "cs_symcut_labels": (c_int, [vp, POINTER(c_int64), c_int, POINTER(c_int32), vp, vp, vp]),
+        "cs_prof_enable": (None, [c_int]),
+        "cs_prof_reset": (None, []),
+        "cs_prof_get": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),
+        "cs_pool_trim": (None, []),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def header_symbols():
+    """Names of every function include/corsair_hip.h declares (used by the CPU-side ABI test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load libcorsair_hip.so; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise CorsairHipError(load().cs_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def require_gpu():
+    if load().cs_device_count() < 1:
+        raise CorsairHipError("no HIP device visible: the corsair_amd hot path has no CPU fallback")
+
+
+# ---- small helpers used by the host modules -------------------------------------------------
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i64_array(values):
+    arr = (c_int64 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def i32_array(values):
+    arr = (c_int32 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def prof_enable(on=True):
+    load().cs_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().cs_prof_reset()
+
+
+def prof_get(name):
+    ms = c_double(0.0)
+    n = c_int64(0)
+    check(load().cs_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value

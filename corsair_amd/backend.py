@@ -1,0 +1,306 @@
+"""Thin torch-tensor front ends of the C ABI (include/corsair_hip.h).
+
+Everything here launches hand-written HIP kernels through libcorsair_hip.so; torch only owns the
+device buffers and the stream.  No CPU fallback: inputs must be CUDA(HIP) tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, i32_array, i64_array, ptr, stream_ptr
+
+KERNEL_VOLUME = 27
+
+
+def _dev(t, dtype, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.CorsairHipError(f"{what} must be a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{what} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _rows(t, what):
+    """(tensor, leading dimension) of a 2-D tensor whose rows are contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{what} must be 2-D with unit inner stride")
+    return t, t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+class CoordMap:
+    """Owns one cs_coordmap handle (coordinates of one tensor stride + hash index)."""
+
+    def __init__(self, handle, device):
+        self._h = c_void_p(handle)
+        self.device = device
+        lib = _lib.load()
+        self.n = int(lib.cs_coordmap_size(self._h))
+        self.tensor_stride = int(lib.cs_coordmap_tensor_stride(self._h))
+        self._coords = None
+
+    @classmethod
+    def create(cls, coords, tensor_stride=1):
+        _lib.require_gpu()
+        coords = _dev(coords, torch.int32, "coordinates").contiguous()
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("coordinates must be int32 [N, 4] (batch, x, y, z)")
+        out = c_void_p()
+        check(_lib.load().cs_coordmap_create(ptr(coords), coords.shape[0], tensor_stride,
+                                             stream_ptr(), ctypes.byref(out)))
+        return cls(out.value, coords.device)
+
+    def stride(self, s=2):
+        out = c_void_p()
+        check(_lib.load().cs_coordmap_stride(self._h, s, stream_ptr(), ctypes.byref(out)))
+        return CoordMap(out.value, self.device)
+
+    @property
+    def coords(self):
+        """int32 [n,4] device tensor (a copy owned by torch)."""
+        if self._coords is None:
+            t = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            if self.n:
+                src = _lib.load().cs_coordmap_coords(self._h)
+                _hip_memcpy_d2d(t.data_ptr(), src, self.n * 16)
+            self._coords = t
+        return self._coords
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cs_coordmap_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _hip_memcpy_d2d(dst, src, nbytes):
+    # tiny helper through torch: wrap the library-owned memory without taking ownership
+    import ctypes as C
+
+    hip = _hip_runtime()
+    rc = hip.hipMemcpyAsync(c_void_p(dst), c_void_p(src), C.c_size_t(nbytes), 3,
+                            c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise _lib.CorsairHipError(f"hipMemcpyAsync failed with {rc}")
+
+
+_hip = None
+
+
+def _hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+    return _hip
+
+
+class KernelMap:
+    """Owns one cs_kernelmap handle (int32 [n_out,27] neighbour table on the device)."""
+
+    def __init__(self, handle, in_map, out_map, transposed):
+        self._h = c_void_p(handle)
+        lib = _lib.load()
+        self.n_out = int(lib.cs_kernelmap_rows(self._h))
+        self.n_in = in_map.n
+        self.num_pairs = int(lib.cs_kernelmap_num_pairs(self._h))
+        self.transposed = transposed
+        self.device = in_map.device
+
+    @classmethod
+    def build(cls, in_map, out_map, kernel_size=3, transposed=False):
+        out = c_void_p()
+        check(_lib.load().cs_kernelmap_build(in_map._h, out_map._h, kernel_size,
+                                             1 if transposed else 0, stream_ptr(),
+                                             ctypes.byref(out)))
+        return cls(out.value, in_map, out_map, transposed)
+
+    def export(self):
+        """Canonical (k, in_row, out_row) int32 triples sorted by (k, out_row)."""
+        n = max(self.num_pairs, 1)
+        k = torch.empty(n, dtype=torch.int32, device=self.device)
+        i = torch.empty(n, dtype=torch.int32, device=self.device)
+        o = torch.empty(n, dtype=torch.int32, device=self.device)
+        got = check(_lib.load().cs_kernelmap_export(self._h, ptr(k), ptr(i), ptr(o), n, stream_ptr()))
+        return k[:got], i[:got], o[:got]
+
+    def table(self):
+        t = torch.empty((self.n_out, KERNEL_VOLUME), dtype=torch.int32, device=self.device)
+        if self.n_out:
+            _hip_memcpy_d2d(t.data_ptr(), _lib.load().cs_kernelmap_table(self._h), self.n_out * 27 * 4)
+        return t
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cs_kernelmap_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def conv_fwd(kmap, x, weight, scale=None, shift=None, residual=None, relu=False, out=None,
+             n_out=None):
+    """Sparse convolution forward with fused epilogue (cs_conv_fwd).  x/out/residual may be column
+    slices of wider row-major buffers."""
+    x, ld_in = _rows(_dev(x, torch.float32, "input features"), "input features")
+    weight = _dev(weight, torch.float32, "kernel").contiguous()
+    if weight.dim() == 2:
+        cin, cout = weight.shape
+    else:
+        cin, cout = weight.shape[1], weight.shape[2]
+    if x.shape[1] != cin:
+        raise ValueError(f"input has {x.shape[1]} channels, kernel expects {cin}")
+    n_in = x.shape[0]
+    if kmap is None:
+        n_out = n_in
+    else:
+        n_out = kmap.n_out
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    out, ld_out = _rows(out, "output")
+    if out.shape[0] != n_out or out.shape[1] != cout:
+        raise ValueError("output buffer has the wrong shape")
+    ld_res = 0
+    if residual is not None:
+        residual, ld_res = _rows(_dev(residual, torch.float32, "residual"), "residual")
+    check(_lib.load().cs_conv_fwd(kmap._h if kmap is not None else None, n_in, n_out, ptr(x), ld_in,
+                                  cin, ptr(weight), cout, ptr(scale), ptr(shift), ptr(residual),
+                                  ld_res, 1 if relu else 0, ptr(out), ld_out, stream_ptr()))
+    return out
+
+
+def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
+    x, ld_in = _rows(_dev(x, torch.float32, "input"), "input")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    out, ld_out = _rows(out, "output")
+    ld_res = 0
+    if residual is not None:
+        residual, ld_res = _rows(residual, "residual")
+    check(_lib.load().cs_affine_act(x.shape[0], x.shape[1], ptr(x), ld_in, ptr(scale), ptr(shift),
+                                    ptr(residual), ld_res, 1 if relu else 0, ptr(out), ld_out,
+                                    stream_ptr()))
+    return out
+
+
+def row_l2_normalize(x, eps=0.0, out=None):
+    x, ld_in = _rows(_dev(x, torch.float32, "input"), "input")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    out, ld_out = _rows(out, "output")
+    check(_lib.load().cs_row_l2_normalize(x.shape[0], x.shape[1], ptr(x), ld_in, float(eps), ptr(out),
+                                          ld_out, stream_ptr()))
+    return out
+
+
+def segmented_max(x, coords, n_batch):
+    """Per-sample column max; `coords` is the int32 [n,4] coordinate tensor (batch in column 0)."""
+    x, ld_in = _rows(_dev(x, torch.float32, "input"), "input")
+    coords = _dev(coords, torch.int32, "coords")
+    out = torch.empty((n_batch, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_lib.load().cs_segmented_max(x.shape[0], x.shape[1], ptr(x), ld_in, ptr(coords),
+                                       coords.stride(0), n_batch, ptr(out), stream_ptr()))
+    return out
+
+
+def voxelize(xyz, offsets, voxel_size):
+    """cs_voxelize: xyz f32 [n,3] device, offsets host list.  Returns (keep_idx int64 [m],
+    grid int32 [m,4], out_offsets list)."""
+    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    n = xyz.shape[0]
+    nseg = len(offsets) - 1
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=xyz.device)
+    grid = torch.empty((max(n, 1), 4), dtype=torch.int32, device=xyz.device)
+    h_off = i64_array(offsets)
+    h_out = (ctypes.c_int64 * (nseg + 1))()
+    check(_lib.load().cs_voxelize(ptr(xyz), h_off, nseg, float(voxel_size), ptr(keep), ptr(grid),
+                                  h_out, stream_ptr()))
+    out_off = [int(v) for v in h_out]
+    m = out_off[-1]
+    return keep[:m], grid[:m], out_off
+
+
+def l2_topk(q, x, k, return_distance=False):
+    q = _dev(q, torch.float32, "queries").contiguous()
+    x = _dev(x, torch.float32, "catalog").contiguous()
+    idx = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
+    dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=q.device) if return_distance else None
+    check(_lib.load().cs_l2_topk(ptr(q), q.shape[0], ptr(x), x.shape[0], q.shape[1], k, ptr(idx),
+                                 ptr(dist), stream_ptr()))
+    return (idx, dist) if return_distance else idx
+
+
+def knn_feat(qf, qoff, tf, toff, k, qlabel=None, tlabel=None, perm=None, return_distance=False):
+    """Batched feature k-NN.  qoff/toff are host offset lists (n_prob+1).  perm: int32 [n_prob,8]
+    device tensor when labels are used."""
+    qf = _dev(qf, torch.float32, "query features").contiguous()
+    tf = _dev(tf, torch.float32, "target features").contiguous()
+    n_prob = len(qoff) - 1
+    idx = torch.empty((qf.shape[0], k), dtype=torch.int32, device=qf.device)
+    dist = torch.empty((qf.shape[0], k), dtype=torch.float64, device=qf.device) if return_distance else None
+    check(_lib.load().cs_knn_feat(ptr(qf), i64_array(qoff), ptr(tf), i64_array(toff), n_prob,
+                                  qf.shape[1], k, ptr(qlabel), ptr(tlabel), ptr(perm), ptr(idx),
+                                  ptr(dist), stream_ptr()))
+    return (idx, dist) if return_distance else idx
+
+
+def chamfer_1dir(src, soff, tgt, toff, src_seg, tgt_seg, T):
+    """Batched one-directional Chamfer; T f32 [n_prob,4,4] device.  Returns f64 [n_prob]."""
+    src = _dev(src, torch.float32, "source").contiguous()
+    tgt = _dev(tgt, torch.float32, "target").contiguous()
+    T = _dev(T, torch.float32, "transforms").contiguous()
+    n_prob = len(src_seg)
+    out = torch.empty(n_prob, dtype=torch.float64, device=src.device)
+    check(_lib.load().cs_chamfer_1dir(ptr(src), i64_array(soff), ptr(tgt), i64_array(toff),
+                                      i32_array(src_seg), i32_array(tgt_seg), n_prob, ptr(T), ptr(out),
+                                      stream_ptr()))
+    return out
+
+
+def ransac_batch(src, tgt, offsets, max_corr, ransac_n=10, max_iter=100000, confidence=0.999, seed=0):
+    """Batched correspondence RANSAC.  Returns (T f32 [n,4,4], inliers int32, rmse f64, iters int32)."""
+    src = _dev(src, torch.float32, "source correspondences").contiguous()
+    tgt = _dev(tgt, torch.float32, "target correspondences").contiguous()
+    n_prob = len(offsets) - 1
+    dev = src.device
+    T = torch.empty((n_prob, 4, 4), dtype=torch.float32, device=dev)
+    inl = torch.empty(n_prob, dtype=torch.int32, device=dev)
+    rmse = torch.empty(n_prob, dtype=torch.float64, device=dev)
+    iters = torch.empty(n_prob, dtype=torch.int32, device=dev)
+    check(_lib.load().cs_ransac_batch(ptr(src), ptr(tgt), i64_array(offsets), n_prob, float(max_corr),
+                                      ransac_n, max_iter, float(confidence), int(seed), ptr(T),
+                                      ptr(inl), ptr(rmse), ptr(iters), stream_ptr()))
+    return T, inl, rmse, iters
+
+
+def symcut_fit(feat, xyz, offsets, anchors, Ks, n_nn=50, n_init=10, max_iter=300, seed=0):
+    """anchors int32 [n_cloud, n_anchor] device; Ks host list.  Returns centers f64 [c,a,4,3],
+    counts int32 [c,a,4], min centre distance f64 [c,a], max error f64 [c,a]."""
+    feat = _dev(feat, torch.float32, "features").contiguous()
+    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    anchors = _dev(anchors, torch.int32, "anchors").contiguous()
+    nc, na = anchors.shape
+    dev = feat.device
+    centers = torch.empty((nc, na, 4, 3), dtype=torch.float64, device=dev)
+    counts = torch.empty((nc, na, 4), dtype=torch.int32, device=dev)
+    mcd = torch.empty((nc, na), dtype=torch.float64, device=dev)
+    mer = torch.empty((nc, na), dtype=torch.float64, device=dev)
+    check(_lib.load().cs_symcut_fit(ptr(feat), feat.shape[1], ptr(xyz), i64_array(offsets), nc,
+                                    ptr(anchors), na, i32_array(Ks), n_nn, n_init, max_iter, int(seed),
+                                    ptr(centers), ptr(counts), ptr(mcd), ptr(mer), stream_ptr()))
+    return centers, counts, mcd, mer
+
+
+def symcut_labels(xyz, offsets, Ks, sel_centers):
+    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    sel_centers = _dev(sel_centers, torch.float64, "centres").contiguous()
+    labels = torch.empty(xyz.shape[0], dtype=torch.int32, device=xyz.device)
+    check(_lib.load().cs_symcut_labels(ptr(xyz), i64_array(offsets), len(Ks), i32_array(Ks),
+                                       ptr(sel_centers), ptr(labels), stream_ptr()))
+    return labels

@@ -1,0 +1,118 @@
+// Internal helpers shared by the translation units of libcorsair_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/corsair_hip.h"
+
+namespace cs {
+
+void set_error(const char* fmt, ...);
+
+#define CS_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      cs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                    __LINE__);                                                          \
+      return CS_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define CS_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      cs::set_error(__VA_ARGS__);     \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define CS_LAUNCH_CHECK() CS_HIP_CHECK(hipGetLastError())
+
+// Size-class caching device allocator for library-owned scratch and map storage.
+void* pool_alloc(size_t bytes);
+void pool_free(void* p);
+
+template <typename T>
+struct PoolBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  PoolBuf() = default;
+  explicit PoolBuf(size_t count) { alloc(count); }
+  PoolBuf(const PoolBuf&) = delete;
+  PoolBuf& operator=(const PoolBuf&) = delete;
+  ~PoolBuf() { release(); }
+  bool alloc(size_t count) {
+    release();
+    n = count;
+    p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+    return p != nullptr;
+  }
+  void release() {
+    if (p) pool_free(p);
+    p = nullptr;
+    n = 0;
+  }
+  T* take() {
+    T* r = p;
+    p = nullptr;
+    n = 0;
+    return r;
+  }
+};
+
+// Pinned host staging buffer (reused, grows).  Not thread safe across host threads by design:
+// the reference drives this path from one Python thread (SURVEY 8b "Threading").
+void* pinned_scratch(size_t bytes, int slot);
+
+// Profiling (cs_prof_*).
+struct ProfScope {
+  int id;
+  hipStream_t stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(const char* name, hipStream_t s);
+  ~ProfScope();
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- coordinate packing ---------------------------------------------------------------
+// key = batch(16) | x+32768 (16) | y+32768 (16) | z+32768 (16)
+__host__ __device__ static inline uint64_t pack_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(x + 32768) << 32) |
+         ((uint64_t)(uint16_t)(y + 32768) << 16) | (uint64_t)(uint16_t)(z + 32768);
+}
+__host__ __device__ static inline bool coord_in_range(int b, int x, int y, int z) {
+  return b >= 0 && b < 65536 && x > -32768 && x < 32768 && y > -32768 && y < 32768 &&
+         z > -32768 && z < 32768;
+}
+__host__ __device__ static inline uint64_t hash64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+static constexpr uint64_t kEmptyKey = ~0ULL;
+
+}  // namespace cs
+
+struct cs_coordmap {
+  int64_t n = 0;
+  int tensor_stride = 1;
+  int32_t* d_coords = nullptr;   // [n,4]
+  uint64_t* d_keys = nullptr;    // [capacity]
+  int32_t* d_vals = nullptr;     // [capacity]
+  uint64_t capacity = 0;         // power of two
+};
+
+struct cs_kernelmap {
+  int64_t n_out = 0, n_in = 0;
+  int kvol = 27;
+  int transposed = 0;
+  int32_t* d_nbr = nullptr;  // [n_out, kvol]
+  int64_t num_pairs = -1;
+};

@@ -1,0 +1,472 @@
+// Exact nearest-neighbour searches of the CORSAIR post-processing path, all in f64 so that the
+// returned indices equal those of the reference's SciPy f64 routines:
+//   cs_l2_topk      <- scipy cdist + argsort            (utils/retrieval.py:139-177)
+//   cs_knn_feat     <- KDTree(feat1).query(feat0, k)     (utils/find_nn.py:43-49, utils/eval_pose.py:48-79,
+//                                                         utils/symmetry.py:145-179)
+//   cs_chamfer_1dir <- apply_transform + KDTree 1-NN     (utils/preprocess.py:39-48,67-70)
+// Distances are evaluated as one fma chain over the feature dimension in ascending order; ties go
+// to the smaller index.  These kernels are VALU(f64)-bound with every operand staged through LDS
+// (targets) or held in registers (queries); HBM traffic is the algorithmic minimum (each row read
+// once per query tile).
+#include <vector>
+
+#include "common.h"
+
+namespace cs {
+
+// ------------------------------------------------------------------------------------------
+// feature k-NN
+// ------------------------------------------------------------------------------------------
+struct KnnWork {
+  int64_t q0;   // first query row of the tile (global)
+  int64_t t0;   // first target row of the problem (global)
+  int32_t qn;   // query rows in this tile (<= 256)
+  int32_t tn;   // target rows
+  int32_t prob;
+  int32_t pad;
+};
+
+constexpr int KNN_MAXK = 8;
+constexpr int KNN_TT = 128;  // target rows per LDS tile
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ work,
+                                                  const float* __restrict__ qf,
+                                                  const float* __restrict__ tf, int k,
+                                                  const int32_t* __restrict__ qlabel,
+                                                  const int32_t* __restrict__ tlabel,
+                                                  const int32_t* __restrict__ perm,
+                                                  int32_t* __restrict__ out_idx,
+                                                  double* __restrict__ out_dist) {
+  __shared__ float t_lds[KNN_TT * DIM];
+  __shared__ int32_t tl_lds[KNN_TT];
+  const KnnWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const bool active = tid < wk.qn;
+  const int64_t qrow = wk.q0 + (active ? tid : 0);
+
+  double q[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) q[c] = (double)qf[qrow * DIM + c];
+  int want = -1;
+  const bool use_labels = qlabel != nullptr;
+  if (use_labels) {
+    int ql = qlabel[qrow];
+    want = (ql >= 0 && ql < 8) ? perm[wk.prob * 8 + ql] : -2;
+  }
+
+  double bd[KNN_MAXK];
+  int32_t bi[KNN_MAXK];
+#pragma unroll
+  for (int j = 0; j < KNN_MAXK; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = -1;
+  }
+
+  for (int tbase = 0; tbase < wk.tn; tbase += KNN_TT) {
+    const int tcount = min(KNN_TT, wk.tn - tbase);
+    __syncthreads();
+    for (int i = tid; i < tcount * DIM; i += 256) t_lds[i] = tf[(wk.t0 + tbase) * DIM + i];
+    if (use_labels)
+      for (int i = tid; i < tcount; i += 256) tl_lds[i] = tlabel[wk.t0 + tbase + i];
+    __syncthreads();
+    if (!active) continue;
+    for (int j = 0; j < tcount; ++j) {
+      if (use_labels && tl_lds[j] != want) continue;
+      double d = 0.0;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        double diff = q[c] - (double)t_lds[j * DIM + c];
+        d = fma(diff, diff, d);
+      }
+      if (d < bd[KNN_MAXK - 1]) {
+        // insert (d, tbase + j) into the running top-8 (ascending); strict < keeps the earlier
+        // index on ties.  The first k entries are the answer.
+        double cd = d;
+        int32_t ci = tbase + j;
+#pragma unroll
+        for (int s = 0; s < KNN_MAXK; ++s) {
+          if (cd < bd[s]) {
+            double td = bd[s];
+            int32_t ti = bi[s];
+            bd[s] = cd;
+            bi[s] = ci;
+            cd = td;
+            ci = ti;
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+    for (int j = 0; j < k; ++j) {
+      // (unrolled select keeps bd/bi in registers)
+      double dj = INFINITY;
+      int32_t ij = -1;
+#pragma unroll
+      for (int s = 0; s < KNN_MAXK; ++s)
+        if (s == j) {
+          dj = bd[s];
+          ij = bi[s];
+        }
+      out_idx[qrow * k + j] = ij;
+      if (out_dist) out_dist[qrow * k + j] = ij >= 0 ? sqrt(dj) : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// descriptor distance matrix + row top-k
+// ------------------------------------------------------------------------------------------
+constexpr int DM_QT = 16;   // queries per block
+constexpr int DM_CT = 64;   // catalog rows per block
+constexpr int DM_DC = 64;   // feature chunk staged in LDS
+
+// D2[q, x] = sum_c (q_c - x_c)^2 in f64, c ascending.  thread = (catalog row j, query group g of 4).
+__global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ Q, int64_t nq,
+                                                     const float* __restrict__ X, int64_t nx,
+                                                     int d, int64_t x_begin, int64_t x_count,
+                                                     double* __restrict__ D2) {
+  __shared__ float q_lds[DM_QT * DM_DC];
+  __shared__ float x_lds[DM_DC * (DM_CT + 1)];
+  const int tid = threadIdx.x;
+  const int j = tid & 63;
+  const int g = tid >> 6;
+  const int64_t q0 = (int64_t)blockIdx.y * DM_QT;
+  const int64_t xl0 = (int64_t)blockIdx.x * DM_CT;  // local to the slab
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c0 = 0; c0 < d; c0 += DM_DC) {
+    const int dc = min(DM_DC, d - c0);
+    __syncthreads();
+    for (int i = tid; i < DM_QT * DM_DC; i += 256) {
+      int r = i / DM_DC, c = i - r * DM_DC;
+      float v = 0.f;
+      if (q0 + r < nq && c < dc) v = Q[(q0 + r) * d + c0 + c];
+      q_lds[i] = v;
+    }
+    for (int i = tid; i < DM_CT * DM_DC; i += 256) {
+      int r = i / DM_DC, c = i - r * DM_DC;
+      float v = 0.f;
+      if (xl0 + r < x_count && c < dc) v = X[(x_begin + xl0 + r) * d + c0 + c];
+      x_lds[c * (DM_CT + 1) + r] = v;
+    }
+    __syncthreads();
+    for (int c = 0; c < dc; ++c) {
+      double xv = (double)x_lds[c * (DM_CT + 1) + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double diff = (double)q_lds[(g * 4 + u) * DM_DC + c] - xv;
+        acc[u] = fma(diff, diff, acc[u]);
+      }
+    }
+  }
+  if (xl0 + j < x_count) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t qi = q0 + g * 4 + u;
+      if (qi < nq) D2[qi * x_count + xl0 + j] = acc[u];
+    }
+  }
+}
+
+constexpr int TK_CAP = 2048;  // LDS sort capacity (entries)
+
+__device__ __forceinline__ bool key_less(unsigned long long da, int ia, unsigned long long db,
+                                         int ib) {
+  return da < db || (da == db && ia < ib);
+}
+
+// One block per query: merge the carried top-k with a slab of squared distances by a bitonic sort
+// of (distance bits, index) in LDS.  carry_* hold k entries per query (distance = +inf when unset).
+__global__ __launch_bounds__(256) void k_row_topk(const double* __restrict__ D2, int64_t x_count,
+                                                  int64_t x_begin, int k,
+                                                  unsigned long long* carry_d, int* carry_i) {
+  __shared__ unsigned long long sd[TK_CAP];
+  __shared__ int si[TK_CAP];
+  const int tid = threadIdx.x;
+  const int64_t qi = blockIdx.x;
+  const unsigned long long INF_BITS = 0x7ff0000000000000ULL;
+  for (int64_t base = 0; base < x_count; base += TK_CAP - k) {
+    const int cnt = (int)min((int64_t)(TK_CAP - k), x_count - base);
+    __syncthreads();
+    for (int i = tid; i < TK_CAP; i += 256) {
+      unsigned long long dv = INF_BITS;
+      int iv = 0x7fffffff;
+      if (i < k) {
+        dv = carry_d[qi * k + i];
+        iv = carry_i[qi * k + i];
+      } else if (i - k < cnt) {
+        dv = (unsigned long long)__double_as_longlong(D2[qi * x_count + base + (i - k)]);
+        iv = (int)(x_begin + base + (i - k));
+      }
+      sd[i] = dv;
+      si[i] = iv;
+    }
+    __syncthreads();
+    for (int size = 2; size <= TK_CAP; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < TK_CAP / 2; t += 256) {
+          int lo = (t / stride) * stride * 2 + (t % stride);
+          int hi = lo + stride;
+          bool up = ((lo & size) == 0);
+          unsigned long long dl = sd[lo], dh = sd[hi];
+          int il = si[lo], ih = si[hi];
+          bool swap = up ? key_less(dh, ih, dl, il) : key_less(dl, il, dh, ih);
+          if (swap) {
+            sd[lo] = dh;
+            si[lo] = ih;
+            sd[hi] = dl;
+            si[hi] = il;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < k; i += 256) {
+      carry_d[qi * k + i] = sd[i];
+      carry_i[qi * k + i] = si[i];
+    }
+  }
+}
+
+__global__ void k_topk_init(unsigned long long* carry_d, int* carry_i, int64_t n) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) {
+    carry_d[t] = 0x7ff0000000000000ULL;
+    carry_i[t] = 0x7fffffff;
+  }
+}
+__global__ void k_topk_finish(const unsigned long long* carry_d, const int* carry_i, int64_t n,
+                              int64_t* idx, double* dist) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) {
+    int i = carry_i[t];
+    idx[t] = i == 0x7fffffff ? -1 : (int64_t)i;
+    if (dist) dist[t] = sqrt(__longlong_as_double((long long)carry_d[t]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// one-directional Chamfer
+// ------------------------------------------------------------------------------------------
+struct ChamferWork {
+  int64_t s0;   // first source row of this tile (global)
+  int64_t t0;   // first target row (global)
+  int32_t sn;   // source rows in this tile (<= 256)
+  int32_t tn;   // target rows
+  int32_t prob;
+  int32_t slot; // index into the partial-sum array
+};
+
+constexpr int CH_TT = 512;
+
+__global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__ work,
+                                                 const float* __restrict__ src,
+                                                 const float* __restrict__ tgt,
+                                                 const float* __restrict__ T,
+                                                 double* __restrict__ partial) {
+  __shared__ float t_lds[CH_TT * 3];
+  __shared__ double red[256];
+  const ChamferWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const bool active = tid < wk.sn;
+  const float* Tp = T + (int64_t)wk.prob * 16;
+  double px = 0, py = 0, pz = 0;
+  if (active) {
+    const float* s = src + (wk.s0 + tid) * 3;
+    double x = s[0], y = s[1], z = s[2];
+    // row-major 4x4: p = R x + t, evaluated as fma(r0,x, fma(r1,y, fma(r2,z, t)))
+    px = fma((double)Tp[0], x, fma((double)Tp[1], y, fma((double)Tp[2], z, (double)Tp[3])));
+    py = fma((double)Tp[4], x, fma((double)Tp[5], y, fma((double)Tp[6], z, (double)Tp[7])));
+    pz = fma((double)Tp[8], x, fma((double)Tp[9], y, fma((double)Tp[10], z, (double)Tp[11])));
+  }
+  double best = INFINITY;
+  for (int tbase = 0; tbase < wk.tn; tbase += CH_TT) {
+    const int tcount = min(CH_TT, wk.tn - tbase);
+    __syncthreads();
+    for (int i = tid; i < tcount * 3; i += 256) t_lds[i] = tgt[(wk.t0 + tbase) * 3 + i];
+    __syncthreads();
+    if (!active) continue;
+    for (int j = 0; j < tcount; ++j) {
+      double dx = px - (double)t_lds[3 * j + 0];
+      double dy = py - (double)t_lds[3 * j + 1];
+      double dz = pz - (double)t_lds[3 * j + 2];
+      double d = fma(dz, dz, fma(dy, dy, dx * dx));
+      best = d < best ? d : best;
+    }
+  }
+  red[tid] = active ? sqrt(best) : 0.0;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) partial[wk.slot] = red[0];
+}
+
+__global__ void k_chamfer_finish(const double* __restrict__ partial,
+                                 const int32_t* __restrict__ slot_begin,
+                                 const int64_t* __restrict__ src_count, int n_prob,
+                                 double* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_prob) return;
+  double s = 0.0;
+  for (int i = slot_begin[p]; i < slot_begin[p + 1]; ++i) s += partial[i];
+  out[p] = src_count[p] > 0 ? s / (double)src_count[p] : NAN;
+}
+
+template <typename T>
+static int upload(PoolBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
+  if (!buf.alloc(host.size())) return CS_ERR_HIP;
+  if (!host.empty())
+    CS_HIP_CHECK(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T),
+                                hipMemcpyHostToDevice, s));
+  // pageable source: the runtime has staged the bytes when the call returns
+  return CS_OK;
+}
+
+}  // namespace cs
+
+using namespace cs;
+
+extern "C" {
+
+int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
+                const int64_t* h_toff, int n_prob, int dim, int k, const int32_t* d_qlabel,
+                const int32_t* d_tlabel, const int32_t* d_perm, int32_t* d_idx, double* d_dist,
+                void* stream) {
+  CS_REQUIRE(d_qf && d_tf && h_qoff && h_toff && d_idx, CS_ERR_INVALID,
+             "cs_knn_feat: NULL argument");
+  CS_REQUIRE(k >= 1 && k <= KNN_MAXK, CS_ERR_UNSUPPORTED, "cs_knn_feat: k = %d not in [1, %d]", k,
+             KNN_MAXK);
+  CS_REQUIRE(dim == 16 || dim == 32 || dim == 3, CS_ERR_UNSUPPORTED,
+             "cs_knn_feat: feature dimension %d not supported (3, 16, 32)", dim);
+  CS_REQUIRE((d_qlabel == nullptr) == (d_tlabel == nullptr) &&
+                 (d_qlabel == nullptr) == (d_perm == nullptr),
+             CS_ERR_INVALID, "cs_knn_feat: labels and perm must be given together");
+  if (n_prob <= 0) return CS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<KnnWork> work;
+  for (int p = 0; p < n_prob; ++p) {
+    int64_t qn = h_qoff[p + 1] - h_qoff[p], tn = h_toff[p + 1] - h_toff[p];
+    CS_REQUIRE(qn >= 0 && tn >= 0 && tn < (1LL << 31), CS_ERR_INVALID,
+               "cs_knn_feat: bad segment in problem %d", p);
+    for (int64_t q = 0; q < qn; q += 256) {
+      KnnWork w;
+      w.q0 = h_qoff[p] + q;
+      w.t0 = h_toff[p];
+      w.qn = (int32_t)(qn - q < 256 ? qn - q : 256);
+      w.tn = (int32_t)tn;
+      w.prob = p;
+      w.pad = 0;
+      work.push_back(w);
+    }
+  }
+  if (work.empty()) return CS_OK;
+  PoolBuf<KnnWork> dwork;
+  int rc = upload(dwork, work, s);
+  if (rc) return rc;
+  {
+    ProfScope prof("knn", s);
+    dim3 grid((unsigned)work.size());
+    if (dim == 16)
+      hipLaunchKernelGGL((k_knn_feat<16>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
+                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist);
+    else if (dim == 32)
+      hipLaunchKernelGGL((k_knn_feat<32>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
+                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist);
+    else
+      hipLaunchKernelGGL((k_knn_feat<3>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k, d_qlabel,
+                         d_tlabel, d_perm, d_idx, d_dist);
+    CS_LAUNCH_CHECK();
+  }
+  CS_HIP_CHECK(hipStreamSynchronize(s));  // dwork returns to the pool
+  return CS_OK;
+}
+
+int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
+               int64_t* d_idx, double* d_dist, void* stream) {
+  CS_REQUIRE(d_q && d_x && d_idx, CS_ERR_INVALID, "cs_l2_topk: NULL argument");
+  CS_REQUIRE(d >= 1 && k >= 1 && k <= 1024 && k <= nx, CS_ERR_INVALID,
+             "cs_l2_topk: need 1 <= k <= min(1024, nx) (k %d, nx %lld)", k, (long long)nx);
+  CS_REQUIRE(nx < (1LL << 31), CS_ERR_UNSUPPORTED, "cs_l2_topk: catalog too large");
+  if (nq == 0) return CS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof("topk", s);
+  // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
+  int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);
+  if (slab < DM_CT) slab = DM_CT;
+  if (slab > nx) slab = nx;
+  PoolBuf<double> D2((size_t)nq * slab);
+  PoolBuf<unsigned long long> cd((size_t)nq * k);
+  PoolBuf<int> ci((size_t)nq * k);
+  CS_REQUIRE(D2.p && cd.p && ci.p, CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
+  hipLaunchKernelGGL(k_topk_init, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
+                     ci.p, nq * k);
+  for (int64_t xb = 0; xb < nx; xb += slab) {
+    int64_t xc = nx - xb < slab ? nx - xb : slab;
+    dim3 grid((unsigned)ceil_div(xc, DM_CT), (unsigned)ceil_div(nq, DM_QT));
+    hipLaunchKernelGGL(k_dist_matrix, grid, dim3(256), 0, s, d_q, nq, d_x, nx, d, xb, xc, D2.p);
+    hipLaunchKernelGGL(k_row_topk, dim3((unsigned)nq), dim3(256), 0, s, D2.p, xc, xb, k, cd.p,
+                       ci.p);
+  }
+  hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
+                     ci.p, nq * k, d_idx, d_dist);
+  CS_LAUNCH_CHECK();
+  CS_HIP_CHECK(hipStreamSynchronize(s));
+  return CS_OK;
+}
+
+int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                    const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                    int n_prob, const float* d_T, double* d_out, void* stream) {
+  CS_REQUIRE(d_src && d_tgt && h_soff && h_toff && h_src_seg && h_tgt_seg && d_T && d_out,
+             CS_ERR_INVALID, "cs_chamfer_1dir: NULL argument");
+  if (n_prob <= 0) return CS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<ChamferWork> work;
+  std::vector<int32_t> slot_begin(n_prob + 1, 0);
+  std::vector<int64_t> src_count(n_prob, 0);
+  for (int p = 0; p < n_prob; ++p) {
+    int ss = h_src_seg[p], ts = h_tgt_seg[p];
+    CS_REQUIRE(ss >= 0 && ts >= 0, CS_ERR_INVALID, "cs_chamfer_1dir: negative segment id");
+    int64_t sn = h_soff[ss + 1] - h_soff[ss], tn = h_toff[ts + 1] - h_toff[ts];
+    CS_REQUIRE(sn >= 0 && tn >= 0 && tn < (1LL << 31), CS_ERR_INVALID,
+               "cs_chamfer_1dir: bad segment in problem %d", p);
+    slot_begin[p] = (int32_t)work.size();
+    src_count[p] = sn;
+    for (int64_t q = 0; q < sn; q += 256) {
+      ChamferWork w;
+      w.s0 = h_soff[ss] + q;
+      w.t0 = h_toff[ts];
+      w.sn = (int32_t)(sn - q < 256 ? sn - q : 256);
+      w.tn = (int32_t)tn;
+      w.prob = p;
+      w.slot = (int32_t)work.size();
+      work.push_back(w);
+    }
+  }
+  slot_begin[n_prob] = (int32_t)work.size();
+  PoolBuf<ChamferWork> dwork;
+  PoolBuf<int32_t> dslot;
+  PoolBuf<int64_t> dcount;
+  PoolBuf<double> partial(work.size() + 1);
+  CS_REQUIRE(partial.p, CS_ERR_HIP, "cs_chamfer_1dir: scratch allocation failed");
+  int rc = upload(dwork, work, s);
+  if (!rc) rc = upload(dslot, slot_begin, s);
+  if (!rc) rc = upload(dcount, src_count, s);
+  if (rc) return rc;
+  {
+    ProfScope prof("chamfer", s);
+    if (!work.empty())
+      hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
+                         d_tgt, d_T, partial.p);
+    hipLaunchKernelGGL(k_chamfer_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
+                       partial.p, dslot.p, dcount.p, n_prob, d_out);
+    CS_LAUNCH_CHECK();
+  }
+  CS_HIP_CHECK(hipStreamSynchronize(s));
+  return CS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// Library runtime: error string, scratch pool, pinned staging, per-kernel-family profiling.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace cs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- pool -------------------------------------------------------------------------------
+static std::mutex g_pool_mu;
+static std::map<size_t, std::vector<void*>> g_free;   // size class -> blocks
+static std::map<void*, size_t> g_live;                // block -> size class
+
+static size_t size_class(size_t bytes) {
+  size_t c = 256;
+  while (c < bytes) c <<= 1;
+  // above 64 MiB round to 16 MiB multiples instead of powers of two (288 GB HBM is large, but
+  // doubling multi-GB tables is still wasteful)
+  if (c > (64u << 20)) {
+    const size_t g = 16u << 20;
+    c = (bytes + g - 1) / g * g;
+  }
+  return c;
+}
+
+void* pool_alloc(size_t bytes) {
+  size_t c = size_class(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_free.find(c);
+    if (it != g_free.end() && !it->second.empty()) {
+      void* p = it->second.back();
+      it->second.pop_back();
+      g_live[p] = c;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, c);
+  if (e != hipSuccess) {
+    cs_pool_trim();
+    e = hipMalloc(&p, c);
+    if (e != hipSuccess) {
+      set_error("hipMalloc(%zu) failed: %s", c, hipGetErrorString(e));
+      return nullptr;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_live[p] = c;
+  return p;
+}
+
+void pool_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_live.find(p);
+  if (it == g_live.end()) return;
+  g_free[it->second].push_back(p);
+  g_live.erase(it);
+}
+
+static void* g_pinned[8] = {nullptr};
+static size_t g_pinned_sz[8] = {0};
+
+void* pinned_scratch(size_t bytes, int slot) {
+  if (slot < 0 || slot >= 8) return nullptr;
+  if (g_pinned_sz[slot] < bytes) {
+    if (g_pinned[slot]) (void)hipHostFree(g_pinned[slot]);
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    if (hipHostMalloc(&g_pinned[slot], c, hipHostMallocDefault) != hipSuccess) {
+      g_pinned[slot] = nullptr;
+      g_pinned_sz[slot] = 0;
+      set_error("hipHostMalloc(%zu) failed", c);
+      return nullptr;
+    }
+    g_pinned_sz[slot] = c;
+  }
+  return g_pinned[slot];
+}
+
+// ---- profiling -----------------------------------------------------------------------------
+static const char* kProfNames[] = {"conv",    "ransac_eval", "ransac_hyp", "knn",
+                                   "chamfer", "topk",        "symcut",     "kmap"};
+static constexpr int kNumProf = sizeof(kProfNames) / sizeof(kProfNames[0]);
+static int g_prof_on = 0;
+struct ProfPending {
+  hipEvent_t e0, e1;
+};
+static std::vector<ProfPending> g_pending[kNumProf];
+static double g_prof_ms[kNumProf] = {0};
+static int64_t g_prof_n[kNumProf] = {0};
+
+static int prof_id(const char* name) {
+  for (int i = 0; i < kNumProf; ++i)
+    if (strcmp(name, kProfNames[i]) == 0) return i;
+  return -1;
+}
+
+ProfScope::ProfScope(const char* name, hipStream_t s) : id(-1), stream(s) {
+  if (!g_prof_on) return;
+  id = prof_id(name);
+  if (id < 0) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    id = -1;
+    return;
+  }
+  (void)hipEventRecord(e0, stream);
+}
+
+ProfScope::~ProfScope() {
+  if (id < 0) return;
+  (void)hipEventRecord(e1, stream);
+  g_pending[id].push_back({e0, e1});
+}
+
+static void prof_drain(int id) {
+  for (auto& p : g_pending[id]) {
+    if (hipEventSynchronize(p.e1) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+        g_prof_ms[id] += ms;
+        g_prof_n[id] += 1;
+      }
+    }
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  g_pending[id].clear();
+}
+
+}  // namespace cs
+
+extern "C" {
+
+const char* cs_last_error(void) { return cs::g_err; }
+
+int cs_version(void) { return 100; }
+
+int cs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void cs_pool_trim(void) {
+  std::lock_guard<std::mutex> lk(cs::g_pool_mu);
+  for (auto& kv : cs::g_free) {
+    for (void* p : kv.second) (void)hipFree(p);
+    kv.second.clear();
+  }
+}
+
+void cs_prof_enable(int on) { cs::g_prof_on = on; }
+
+void cs_prof_reset(void) {
+  for (int i = 0; i < cs::kNumProf; ++i) {
+    cs::prof_drain(i);
+    cs::g_prof_ms[i] = 0;
+    cs::g_prof_n[i] = 0;
+  }
+}
+
+int cs_prof_get(const char* name, double* total_ms, int64_t* launches) {
+  int id = cs::prof_id(name);
+  if (id < 0) {
+    cs::set_error("unknown profile family '%s'", name);
+    return CS_ERR_INVALID;
+  }
+  cs::prof_drain(id);
+  if (total_ms) *total_ms = cs::g_prof_ms[id];
+  if (launches) *launches = cs::g_prof_n[id];
+  return CS_OK;
+}
+
+}  // extern "C"

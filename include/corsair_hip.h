@@ -1,0 +1,220 @@
+/*
+ * corsair_hip.h -- C ABI of libcorsair_hip.so, the MI355X (gfx950) native hot path of
+ * CORSAIR inference: sparse-voxel ResUNet operators, descriptor top-k, feature k-NN,
+ * one-directional Chamfer, batched correspondence RANSAC and the symmetry part-cut.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own:
+ * its hot path sits behind the MinkowskiEngine Python operator API and three Python function
+ * seams (utils/retrieval.py, utils/eval_pose.py, utils/preprocess.py).  Every entry point below
+ * names the reference interface it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer prefixed d_ is a DEVICE pointer owned by the caller
+ *     (e.g. tensor.data_ptr()); h_ is a host pointer.  The library owns only the opaque map
+ *     handles and an internal scratch pool.
+ *   - every call takes the hipStream_t to launch on as a void* (0 = default stream).
+ *   - return value 0 = success, negative = error; cs_last_error() returns the (thread-local)
+ *     message.  The Python host raises RuntimeError(cs_last_error()), mirroring ME's
+ *     RuntimeError on coordinate-key mismatch.
+ *   - rows of feature matrices are addressed with an explicit leading dimension (ld, in
+ *     elements) so a consumer can write straight into a slice of a wider buffer (this is how
+ *     ME.cat -- model/resunet.py:239,246,253 -- is made free).
+ */
+#ifndef CORSAIR_HIP_H
+#define CORSAIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_OK 0
+#define CS_ERR_INVALID (-1)
+#define CS_ERR_HIP (-2)
+#define CS_ERR_RANGE (-3)
+#define CS_ERR_DUPLICATE (-4)
+#define CS_ERR_UNSUPPORTED (-5)
+
+typedef struct cs_coordmap cs_coordmap;   /* coordinates of one tensor stride + hash index */
+typedef struct cs_kernelmap cs_kernelmap; /* output-stationary neighbour table of one conv  */
+
+const char* cs_last_error(void);
+int cs_version(void);
+/* number of visible HIP devices (does not initialise a context) */
+int cs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Coordinate maps.  Replaces ME.SparseTensor(feat, coords) coordinate-manager creation
+ * (evaluation.py:215-218,246-249) and the strided coordinate generation inside
+ * ME.MinkowskiConvolution(stride=2) (model/resunet.py:64-72,80-87,95-103).
+ * d_coords: int32 [n,4] rows (batch, x, y, z), unique, |x|,|y|,|z| < 32768, 0 <= batch < 65536.
+ * Row order of the created map == input order (evaluation.py:227-229 relies on it).
+ * cs_coordmap_stride: output coords = unique rows of floor(c / (s*ts)) * (s*ts), ordered by
+ * FIRST OCCURRENCE in input-row order; new tensor stride s*ts.
+ * ---------------------------------------------------------------------------------------- */
+int cs_coordmap_create(const int32_t* d_coords, int64_t n, int tensor_stride, void* stream,
+                       cs_coordmap** out);
+int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coordmap** out);
+int64_t cs_coordmap_size(const cs_coordmap* m);
+int cs_coordmap_tensor_stride(const cs_coordmap* m);
+const int32_t* cs_coordmap_coords(const cs_coordmap* m); /* device int32 [n,4] */
+void cs_coordmap_free(cs_coordmap* m);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel maps.  Replaces the kernel-map generation + caching of ME's coordinate manager for
+ * kernel_size=3 (27 offsets, k = (dx+1) + 3(dy+1) + 9(dz+1)), dilation 1.
+ *   transposed == 0: out row o gathers in rows at  o + delta_k * ts_in   (ts_out in {ts_in, 2 ts_in})
+ *   transposed == 1: out row o (fine map) gathers in rows (coarse map) at  o - delta_k * ts_out,
+ *                    i.e. the strided map with in/out swapped and the same k
+ *                    (ME.MinkowskiConvolutionTranspose, model/resunet.py:110-118,131-139,152-160).
+ * The table is int32 [n_out, 27], entry = in row or -1.
+ * cs_kernelmap_export writes the canonical (k, in_row, out_row) triples sorted by (k, out_row)
+ * for bit-exact parity tests; returns the number of pairs (or negative error).
+ * ---------------------------------------------------------------------------------------- */
+int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size,
+                       int transposed, void* stream, cs_kernelmap** km);
+int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km);
+int64_t cs_kernelmap_rows(const cs_kernelmap* km);
+const int32_t* cs_kernelmap_table(const cs_kernelmap* km);
+int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in, int32_t* d_out,
+                            int64_t capacity, void* stream);
+void cs_kernelmap_free(cs_kernelmap* km);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution forward with fused epilogue.  Replaces ME.MinkowskiConvolution /
+ * ME.MinkowskiConvolutionTranspose forward (model/resunet.py:49-193, model/residual_block.py:41-53,
+ * model/fc.py:63-71) and, fused, ME.MinkowskiBatchNorm in eval mode (model/common.py:22),
+ * MEF.relu (model/resunet.py:212-255) and SparseTensor.__iadd__ (model/residual_block.py:70).
+ *   out[o, :] = epilogue( sum_{k ascending} sum_{ci ascending} in[nbr[o][k], ci] * W[k, ci, :] )
+ * accumulated as ONE f32 fma chain in exactly that order (f32-input MFMA is such a chain), then
+ *   v = scale ? fma(v, scale[c], shift[c]) : (shift ? v + shift[c] : v);
+ *   v = residual ? v + residual[o, c] : v;   v = relu ? max(v, 0) : v.
+ * km == NULL means kernel_size 1 (identity map, n_out == n_in, W is [cin, cout]).
+ * ---------------------------------------------------------------------------------------- */
+int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float* d_in, int ld_in,
+                int cin, const float* d_w, int cout, const float* d_scale, const float* d_shift,
+                const float* d_residual, int ld_res, int relu, float* d_out, int ld_out,
+                void* stream);
+
+/* Eval-mode batch-norm / bias / residual / ReLU as a stand-alone op (for the unfused, op-by-op
+ * MinkowskiEngine-compatible path): same epilogue formula as cs_conv_fwd applied to d_in. */
+int cs_affine_act(int64_t n, int c, const float* d_in, int ld_in, const float* d_scale,
+                  const float* d_shift, const float* d_residual, int ld_res, int relu,
+                  float* d_out, int ld_out, void* stream);
+
+/* Row L2 normalisation out = in / max(||in||_2, eps) (eps = 0 reproduces model/resunet.py:260-262;
+ * eps = 1e-12 reproduces nn.functional.normalize at evaluation.py:231,264). */
+int cs_row_l2_normalize(int64_t n, int c, const float* d_in, int ld_in, float eps, float* d_out,
+                        int ld_out, void* stream);
+
+/* Per-sample column-wise max over rows (model/fc.py:23-29,124-125: split_batch + feat.max(0)).
+ * d_batch: int32 batch index of every row, read with stride batch_ld (pass the coords pointer
+ * and 4).  d_out: [n_batch, c]; rows of absent samples are -inf. */
+int cs_segmented_max(int64_t n, int c, const float* d_in, int ld_in, const int32_t* d_batch,
+                     int batch_ld, int n_batch, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxel quantisation.  Replaces ME.utils.sparse_quantize(floor(xyz/voxel), return_index=True,
+ * return_maps_only=True) (utils/Info/CADLib.py:106-121, datasets/CategoryDataset.py:179-197):
+ * for every cloud segment keep the first point of each voxel; kept indices ascending.
+ * d_xyz f32 [n,3]; h_offsets int64 [n_seg+1] (host); d_keep_idx int64 [n] (capacity n, indices
+ * into the concatenated cloud); d_grid int32 [n,4] (batch, x, y, z) of kept rows;
+ * h_out_offsets int64 [n_seg+1] (host) receives the kept segment boundaries.
+ * ---------------------------------------------------------------------------------------- */
+int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
+                int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor retrieval.  Replaces scipy cdist + full argsort at utils/retrieval.py:139-177:
+ * for every query the k catalog rows with the smallest Euclidean distance, ascending, ties
+ * broken by smaller catalog index.  Distances are evaluated in f64 exactly as
+ * sum_c (double(q_c) - double(x_c))^2 (c ascending, fma chain); d_dist receives sqrt of it.
+ * d_q f32 [nq,d], d_x f32 [nx,d]; d_idx int64 [nq,k]; d_dist f64 [nq,k] (may be NULL).
+ * ---------------------------------------------------------------------------------------- */
+int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
+               int64_t* d_idx, double* d_dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched feature k-NN.  Replaces find_knn_cpu / KDTree(feat1).query(feat0, k)
+ * (utils/find_nn.py:43-49) as used by find_kcorr (utils/eval_pose.py:48-79) and split_corr
+ * (utils/symmetry.py:145-179).  Problem p searches, for every row of query segment
+ * [h_qoff[p], h_qoff[p+1]) of d_qf, the k nearest rows of target segment
+ * [h_toff[p], h_toff[p+1]) of d_tf (f64 squared distance, c ascending fma chain, ties ->
+ * smaller index).  Optional part labels restrict the search (split_corr): target row j is a
+ * candidate of query row i iff d_tlabel[j] == d_perm[p*8 + d_qlabel[i]].
+ * d_idx int32 [total_q, k]: target row index LOCAL to the target segment, -1 if fewer than k
+ * candidates.  d_dist f64 [total_q,k] optional.
+ * ---------------------------------------------------------------------------------------- */
+int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
+                const int64_t* h_toff, int n_prob, int dim, int k, const int32_t* d_qlabel,
+                const int32_t* d_tlabel, const int32_t* d_perm, int32_t* d_idx, double* d_dist,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One-directional Chamfer.  Replaces apply_transform + chamfer_kdtree_1direction
+ * (utils/preprocess.py:39-48,67-70): problem p transforms the source segment with the f32
+ * 4x4 row-major matrix d_T[p] (f64 arithmetic), finds for every source point the Euclidean
+ * distance to the nearest target point, writes the mean to d_out[p] (f64).
+ * Source / target segments are selected per problem by index into the offset tables.
+ * ---------------------------------------------------------------------------------------- */
+int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                    const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                    int n_prob, const float* d_T, double* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched correspondence RANSAC.  Replaces registration_based_on_corr ->
+ * o3d.pipelines.registration.registration_ransac_based_on_correspondence(src, tgt, corr,
+ * max_corr, ransac_n=10) (utils/eval_pose.py:82-100).  Problem p owns correspondences
+ * [h_off[p], h_off[p+1]) of d_src/d_tgt (f32 [M,3], pair i = (src_i, tgt_i)).
+ * Semantics = Open3D's loop run on one thread, with a counter-based RNG:
+ *   for itr in [0, max_iter): stop if itr >= est_k; sample ransac_n pairs (with replacement,
+ *   idx = rng(seed, itr, j) mod-free multiply-shift); T = rigid least-squares fit (no scale);
+ *   inliers = #{ |T src_i - tgt_i|^2 < max_corr^2 }, err = sum of inlier squared distances;
+ *   better = more inliers, or equal inliers and smaller err; on improvement
+ *   est_k = min(est_k, ceil(log(1-confidence) / log(1 - (inliers/M)^ransac_n))).
+ * d_T f32 [n_prob,16] row-major 4x4 (identity if no hypothesis had an inlier);
+ * d_inliers int32 [n_prob]; d_rmse f64 [n_prob]; d_iters int32 [n_prob] = iterations consumed.
+ * ---------------------------------------------------------------------------------------- */
+int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off, int n_prob,
+                    float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
+                    float* d_T, int32_t* d_inliers, double* d_rmse, int32_t* d_iters,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Symmetry part cut.  Replaces symmetric_cut4 (utils/symmetry.py:182-259) for a batch of
+ * clouds: for every (cloud, anchor) the 50 feature-nearest voxels, n_init seeded k-means fits
+ * of K centres on their xyz, the statistics the acceptance gate needs, and finally the labels
+ * of every voxel under the accepted model.
+ *   cs_symcut_fit: d_feat f32 [N,dim], d_xyz f32 [N,3], h_off int64 [n_cloud+1],
+ *     d_anchor int32 [n_cloud, n_anchor] (row index local to the cloud), h_K int32 [n_cloud] in {2,4};
+ *     outputs per (cloud, anchor): d_centers f64 [.,4,3], d_counts int32 [.,4] (labels of the WHOLE
+ *     cloud), d_min_center_dist f64, d_max_error f64 (max over clusters of mean distance of the
+ *     50-NN members to their centre).
+ *   cs_symcut_labels: labels of every voxel for the chosen centres (d_sel_centers f64 [n_cloud,4,3]),
+ *     argmin distance, ties -> smaller centre index.
+ * ---------------------------------------------------------------------------------------- */
+int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_t* h_off,
+                  int n_cloud, const int32_t* d_anchor, int n_anchor, const int32_t* h_K,
+                  int n_nn, int n_init, int max_iter, uint64_t seed, double* d_centers,
+                  int32_t* d_counts, double* d_min_center_dist, double* d_max_error,
+                  void* stream);
+int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, const int32_t* h_K,
+                     const double* d_sel_centers, int32_t* d_labels, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Profiling hooks for bench.py: when enabled the library brackets the launches of each named
+ * kernel family with hipEvents on the launch stream and accumulates the elapsed time.
+ * names: "conv", "ransac_eval", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap".
+ * ---------------------------------------------------------------------------------------- */
+void cs_prof_enable(int on);
+void cs_prof_reset(void);
+int cs_prof_get(const char* name, double* total_ms, int64_t* launches);
+
+/* Return all cached scratch memory to the HIP runtime. */
+void cs_pool_trim(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORSAIR_HIP_H */

@@ -1,0 +1,82 @@
+"""GPU parity: coordinate maps, kernel maps and sparse convolution vs the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(gpu, coords):
+    from corsair_amd import engine
+
+    return engine.BatchMaps(torch.from_numpy(coords).to(gpu))
+
+
+def test_coordmaps_and_kernelmaps_bit_exact(gpu):
+    from oracle import resunet as oref
+    from oracle import sparse as osp
+
+    coords, _, _, _ = make_batch([0, 1, 2], n_points=6000)
+    m = _maps(gpu, coords)
+    omaps, okm = oref.build_maps(coords)
+    for name in ("c1", "c2", "c4", "c8"):
+        got = getattr(m, name).coords.cpu().numpy()
+        assert np.array_equal(got, omaps[name]), name
+    for name, nbr in okm.items():
+        km = getattr(m, name)
+        assert np.array_equal(km.table().cpu().numpy(), nbr), name
+        k, i, o = (t.cpu().numpy() for t in km.export())
+        ok, oi, oo = osp.kernel_map_triples(nbr)
+        assert km.num_pairs == len(ok)
+        assert np.array_equal(k, ok) and np.array_equal(i, oi) and np.array_equal(o, oo), name
+
+
+@pytest.mark.parametrize("cin,cout", [(1, 32), (32, 32), (32, 64), (64, 64), (64, 128), (256, 128),
+                                      (96, 64), (64, 16)])
+def test_conv_bit_exact(gpu, oracle_native, cin, cout):
+    from corsair_amd import backend as B
+    from oracle import resunet as oref
+
+    coords, _, _, _ = make_batch([3, 4], n_points=3000)
+    m = _maps(gpu, coords)
+    _, okm = oref.build_maps(coords)
+    rng = np.random.default_rng(cin * 1000 + cout)
+    n = coords.shape[0]
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    want = oracle_native.conv_fwd(okm["s1"], x, w, scale, shift, res, True)
+    got = B.conv_fwd(m.s1, torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu),
+                     torch.from_numpy(scale).to(gpu), torch.from_numpy(shift).to(gpu),
+                     torch.from_numpy(res).to(gpu), True).cpu().numpy()
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+    # strided and transposed maps, no epilogue
+    n2 = m.c2.n
+    w2 = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+    want = oracle_native.conv_fwd(okm["s1_s2"], x, w2)
+    got = B.conv_fwd(m.s1_s2, torch.from_numpy(x).to(gpu), torch.from_numpy(w2).to(gpu)).cpu().numpy()
+    assert got.shape == (n2, cout) and np.array_equal(got, want)
+    x2 = rng.standard_normal((n2, cin)).astype(np.float32)
+    want = oracle_native.conv_fwd(okm["s2_s1_T"], x2, w2)
+    got = B.conv_fwd(m.s2_s1_T, torch.from_numpy(x2).to(gpu), torch.from_numpy(w2).to(gpu)).cpu().numpy()
+    assert got.shape == (n, cout) and np.array_equal(got, want)
+
+
+def test_resunet_forward_bit_exact(gpu, oracle_native):
+    from corsair_amd import engine, synth
+    from oracle import resunet as oref
+
+    coords, feats, _, offsets = make_batch([5, 6, 7], n_points=5000)
+    sd, emb = synth.make_state_dicts(31)
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    out, feat, maps = eng.forward(torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu))
+    g = eng.embed(feat, maps, 3)
+    want_out, want_feat, omaps = oref.resunet_forward(sd, coords, feats)
+    want_g = oref.embedding_forward(emb, want_feat, omaps["c8"][:, 0], 3)
+    assert np.array_equal(feat.cpu().numpy(), want_feat)
+    assert np.array_equal(out.cpu().numpy(), want_out)
+    assert np.array_equal(g.cpu().numpy(), want_g)
