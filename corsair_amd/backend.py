@@ -236,17 +236,23 @@ def l2_topk(q, x, k, return_distance=False):
     return (idx, dist) if return_distance else idx
 
 
-def knn_feat(qf, qoff, tf, toff, k, qlabel=None, tlabel=None, perm=None, return_distance=False):
-    """Batched feature k-NN.  qoff/toff are host offset lists (n_prob+1).  perm: int32 [n_prob,8]
-    device tensor when labels are used."""
+def knn_feat(qf, qoff, tf, toff, k, qseg=None, tseg=None, qlabel=None, tlabel=None, perm=None,
+             return_distance=False):
+    """Batched feature k-NN.  qoff/toff: host offset lists of the segment tables; qseg/tseg: per
+    problem segment ids (default: problem p uses segment p of both).  perm: int32 [n_prob,8] device
+    tensor when labels are used.  Output rows are problem-major."""
     qf = _dev(qf, torch.float32, "query features").contiguous()
     tf = _dev(tf, torch.float32, "target features").contiguous()
-    n_prob = len(qoff) - 1
-    idx = torch.empty((qf.shape[0], k), dtype=torch.int32, device=qf.device)
-    dist = torch.empty((qf.shape[0], k), dtype=torch.float64, device=qf.device) if return_distance else None
-    check(_lib.load().cs_knn_feat(ptr(qf), i64_array(qoff), ptr(tf), i64_array(toff), n_prob,
-                                  qf.shape[1], k, ptr(qlabel), ptr(tlabel), ptr(perm), ptr(idx),
-                                  ptr(dist), stream_ptr()))
+    if qseg is None:
+        qseg = list(range(len(qoff) - 1))
+        tseg = list(range(len(toff) - 1))
+    n_prob = len(qseg)
+    total = sum(int(qoff[s + 1]) - int(qoff[s]) for s in qseg)
+    idx = torch.empty((total, k), dtype=torch.int32, device=qf.device)
+    dist = torch.empty((total, k), dtype=torch.float64, device=qf.device) if return_distance else None
+    check(_lib.load().cs_knn_feat(ptr(qf), i64_array(qoff), ptr(tf), i64_array(toff), i32_array(qseg),
+                                  i32_array(tseg), n_prob, qf.shape[1], k, ptr(qlabel), ptr(tlabel),
+                                  ptr(perm), ptr(idx), ptr(dist), stream_ptr()))
     return (idx, dist) if return_distance else idx
 
 

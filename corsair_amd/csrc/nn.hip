@@ -18,8 +18,9 @@ namespace cs {
 // feature k-NN
 // ------------------------------------------------------------------------------------------
 struct KnnWork {
-  int64_t q0;   // first query row of the tile (global)
-  int64_t t0;   // first target row of the problem (global)
+  int64_t q0;   // first query row of the tile (row of d_qf)
+  int64_t t0;   // first target row of the problem (row of d_tf)
+  int64_t o0;   // first output row of the tile (problem-major)
   int32_t qn;   // query rows in this tile (<= 256)
   int32_t tn;   // target rows
   int32_t prob;
@@ -84,9 +85,11 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
         // index on ties.  The first k entries are the answer.
         double cd = d;
         int32_t ci = tbase + j;
+        bool carry = false;  // once placed, the displaced tail shifts down unconditionally
 #pragma unroll
         for (int s = 0; s < KNN_MAXK; ++s) {
-          if (cd < bd[s]) {
+          if (carry || cd < bd[s]) {
+            carry = true;
             double td = bd[s];
             int32_t ti = bi[s];
             bd[s] = cd;
@@ -109,8 +112,9 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
           dj = bd[s];
           ij = bi[s];
         }
-      out_idx[qrow * k + j] = ij;
-      if (out_dist) out_dist[qrow * k + j] = ij >= 0 ? sqrt(dj) : INFINITY;
+      const int64_t orow = wk.o0 + tid;
+      out_idx[orow * k + j] = ij;
+      if (out_dist) out_dist[orow * k + j] = ij >= 0 ? sqrt(dj) : INFINITY;
     }
   }
 }
@@ -332,10 +336,10 @@ using namespace cs;
 extern "C" {
 
 int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
-                const int64_t* h_toff, int n_prob, int dim, int k, const int32_t* d_qlabel,
-                const int32_t* d_tlabel, const int32_t* d_perm, int32_t* d_idx, double* d_dist,
-                void* stream) {
-  CS_REQUIRE(d_qf && d_tf && h_qoff && h_toff && d_idx, CS_ERR_INVALID,
+                const int64_t* h_toff, const int32_t* h_qseg, const int32_t* h_tseg, int n_prob,
+                int dim, int k, const int32_t* d_qlabel, const int32_t* d_tlabel,
+                const int32_t* d_perm, int32_t* d_idx, double* d_dist, void* stream) {
+  CS_REQUIRE(d_qf && d_tf && h_qoff && h_toff && h_qseg && h_tseg && d_idx, CS_ERR_INVALID,
              "cs_knn_feat: NULL argument");
   CS_REQUIRE(k >= 1 && k <= KNN_MAXK, CS_ERR_UNSUPPORTED, "cs_knn_feat: k = %d not in [1, %d]", k,
              KNN_MAXK);
@@ -347,20 +351,26 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   std::vector<KnnWork> work;
+  int64_t out_row = 0;
   for (int p = 0; p < n_prob; ++p) {
-    int64_t qn = h_qoff[p + 1] - h_qoff[p], tn = h_toff[p + 1] - h_toff[p];
+    CS_REQUIRE(h_qseg[p] >= 0 && h_tseg[p] >= 0, CS_ERR_INVALID,
+               "cs_knn_feat: negative segment id in problem %d", p);
+    const int64_t q0 = h_qoff[h_qseg[p]], t0 = h_toff[h_tseg[p]];
+    int64_t qn = h_qoff[h_qseg[p] + 1] - q0, tn = h_toff[h_tseg[p] + 1] - t0;
     CS_REQUIRE(qn >= 0 && tn >= 0 && tn < (1LL << 31), CS_ERR_INVALID,
                "cs_knn_feat: bad segment in problem %d", p);
     for (int64_t q = 0; q < qn; q += 256) {
       KnnWork w;
-      w.q0 = h_qoff[p] + q;
-      w.t0 = h_toff[p];
+      w.q0 = q0 + q;
+      w.t0 = t0;
+      w.o0 = out_row + q;
       w.qn = (int32_t)(qn - q < 256 ? qn - q : 256);
       w.tn = (int32_t)tn;
       w.prob = p;
       w.pad = 0;
       work.push_back(w);
     }
+    out_row += qn;
   }
   if (work.empty()) return CS_OK;
   PoolBuf<KnnWork> dwork;

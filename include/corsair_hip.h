@@ -138,18 +138,19 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
 /* ------------------------------------------------------------------------------------------
  * Batched feature k-NN.  Replaces find_knn_cpu / KDTree(feat1).query(feat0, k)
  * (utils/find_nn.py:43-49) as used by find_kcorr (utils/eval_pose.py:48-79) and split_corr
- * (utils/symmetry.py:145-179).  Problem p searches, for every row of query segment
- * [h_qoff[p], h_qoff[p+1]) of d_qf, the k nearest rows of target segment
- * [h_toff[p], h_toff[p+1]) of d_tf (f64 squared distance, c ascending fma chain, ties ->
- * smaller index).  Optional part labels restrict the search (split_corr): target row j is a
- * candidate of query row i iff d_tlabel[j] == d_perm[p*8 + d_qlabel[i]].
- * d_idx int32 [total_q, k]: target row index LOCAL to the target segment, -1 if fewer than k
- * candidates.  d_dist f64 [total_q,k] optional.
+ * (utils/symmetry.py:145-179).  The feature matrices are segmented by host offset tables
+ * (h_qoff / h_toff); problem p searches, for every row of query segment h_qseg[p], the k nearest
+ * rows of target segment h_tseg[p] (f64 squared distance, c ascending fma chain, ties -> smaller
+ * index).  Optional part labels (one per feature row) restrict the search (split_corr): target
+ * row j is a candidate of query row i iff d_tlabel[j] == d_perm[p*8 + d_qlabel[i]].
+ * Output rows are problem-major (all rows of problem 0, then problem 1, ...):
+ * d_idx int32 [sum_p nq_p, k] = target row index LOCAL to the target segment, -1 if fewer than k
+ * candidates; d_dist f64 same shape, optional (Euclidean distance).
  * ---------------------------------------------------------------------------------------- */
 int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
-                const int64_t* h_toff, int n_prob, int dim, int k, const int32_t* d_qlabel,
-                const int32_t* d_tlabel, const int32_t* d_perm, int32_t* d_idx, double* d_dist,
-                void* stream);
+                const int64_t* h_toff, const int32_t* h_qseg, const int32_t* h_tseg, int n_prob,
+                int dim, int k, const int32_t* d_qlabel, const int32_t* d_tlabel,
+                const int32_t* d_perm, int32_t* d_idx, double* d_dist, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One-directional Chamfer.  Replaces apply_transform + chamfer_kdtree_1direction

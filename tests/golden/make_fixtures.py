@@ -1,0 +1,146 @@
+"""Generates the golden fixtures under tests/golden/ from the reference tree (run in the build
+container only: /root/reference does not exist on the GPU box).
+
+  python tests/golden/make_fixtures.py
+
+Fixtures are DATA (inputs + expected outputs); no reference source text is stored.
+  eval_pose_kat.npz     known-answer cases for eval_pose (utils/eval_pose.py:103-128) distilled from the
+                        reference's shipped result caches data/cache_{pose,ret}{,_best}/ (written by
+                        evaluation.py:421-441) with T0 = configs/fix_trans.npy[i,0]
+                        (datasets/ScannetDataset.py:274) and T1 = I (utils/Info/CADLib.py:136).
+  aggregate_kat.npz     per-query losses of data/cache_pose_best (chair, top1) + the README table rows
+                        they reproduce (README.md:175-176,215-216) for the metric aggregation
+                        (evaluation.py:334-358).
+  retrieval_kat.npz     outputs of the reference's own utils/retrieval.py (imported here) on seeded
+                        synthetic descriptors and a 160x160 block of configs/03001627_scan2cad.npy.
+  real_clouds.npz       two bundled ShapeNet PC15k test clouds (first 10000 points, f32) used as
+                        realistic inputs for the sparse-path parity tests.
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(OUT))
+sys.path.insert(0, ROOT)
+
+
+def rot_y(theta):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+
+
+def eval_pose_np(T_est, T0, T1, s):
+    best_t, best_r = np.inf, np.inf
+    for i in range(s):
+        trans = np.eye(4)
+        trans[:3, :3] = rot_y(i * (2 * np.pi / s))
+        T_gt = (T1 @ np.linalg.inv(trans) @ np.linalg.inv(T0)).astype(np.float32)
+        tr = np.float64(np.trace(T_est[:3, :3].T @ T_gt[:3, :3]))
+        r = np.arccos(np.clip((tr - 1) / 2, -1, 1))
+        t = np.linalg.norm(T_est[:3, 3] - T_gt[:3, 3])
+        if best_r > r:
+            best_r, best_t = r, t
+    return best_t, best_r
+
+
+def make_eval_pose_kat():
+    fix = np.load(f"{REF}/configs/fix_trans.npy")
+    rows = {"T_est": [], "T0": [], "sym": [], "t": [], "r": [], "src": []}
+    total = matched = 0
+    rng = np.random.default_rng(7)
+    for cache in ("cache_pose", "cache_pose_best", "cache_ret", "cache_ret_best"):
+        for cat in ("chair", "table"):
+            for tgt in ("gt", "top1"):
+                for kind, loss in (("ransac", "ransac"), ("best", "sym")):
+                    d = f"{REF}/data/{cache}"
+                    Ts = np.load(f"{d}/Ts_est_{kind}_{cat}_{tgt}.npy").reshape(-1, 4, 4)
+                    rl = np.load(f"{d}/r_losses_{loss}_{cat}_{tgt}.npy")
+                    tl = np.load(f"{d}/t_losses_{loss}_{cat}_{tgt}.npy")
+                    pick = rng.choice(len(Ts), size=8, replace=False)
+                    for i in range(len(Ts)):
+                        T0 = fix[i, 0]
+                        found = None
+                        for s in (1, 2, 3, 4, 6, 12):
+                            t, r = eval_pose_np(Ts[i].astype(np.float32), T0, np.eye(4), s)
+                            if abs(r - rl[i]) < 1e-4 and abs(t - tl[i]) < 1e-4:
+                                found = s
+                                break
+                        total += 1
+                        matched += found is not None
+                        if found is not None and i in pick:
+                            rows["T_est"].append(Ts[i].astype(np.float32))
+                            rows["T0"].append(T0)
+                            rows["sym"].append(found)
+                            rows["t"].append(tl[i])
+                            rows["r"].append(rl[i])
+                            rows["src"].append(f"{cache}/{kind}_{cat}_{tgt}[{i}]")
+    print(f"eval_pose: restatement reproduces {matched}/{total} cached (t,r) pairs; "
+          f"{len(rows['sym'])} rows kept")
+    np.savez_compressed(f"{OUT}/eval_pose_kat.npz", T_est=np.array(rows["T_est"]),
+                        T0=np.array(rows["T0"]), sym=np.array(rows["sym"], np.int32),
+                        t=np.array(rows["t"], np.float64), r=np.array(rows["r"], np.float64),
+                        src=np.array(rows["src"]), reproduced=np.array([matched, total]))
+
+
+def make_aggregate_kat():
+    d = f"{REF}/data/cache_pose_best"
+    out = {}
+    for k in ("r_losses_ransac", "r_losses_sym", "t_losses_ransac", "t_losses_sym",
+              "chamfer_dist_ransac", "chamfer_dist_sym"):
+        out[k] = np.load(f"{d}/{k}_chair_top1.npy")
+    # README.md:175-176 (RRE mean deg, <=5, <=15, <=45 %) and :215-216 (RTE mean, <=.02,.05,.10,.15 %)
+    out["readme_rre_nosym"] = np.array([39.17, 6.64, 54.78, 80.36])
+    out["readme_rre_sym"] = np.array([38.74, 9.87, 59.82, 81.17])
+    out["readme_rte_nosym"] = np.array([0.28, 0.20, 3.93, 20.95, 43.61])
+    out["readme_rte_sym"] = np.array([0.27, 0.30, 4.53, 23.36, 47.33])
+    np.savez_compressed(f"{OUT}/aggregate_kat.npz", **out)
+
+
+def make_retrieval_kat():
+    sys.path.insert(0, REF)
+    from utils import retrieval as ref_ret  # the reference's own module (imports fine here)
+
+    table = np.load(f"{REF}/configs/03001627_scan2cad.npy")[:160, :160].copy()
+    np.fill_diagonal(table, 0.0)  # datasets/ScannetDataset.py:65-66
+    rng = np.random.default_rng(2024)
+    lib = rng.standard_normal((160, 256)).astype(np.float32)
+    lib /= np.linalg.norm(lib, axis=1, keepdims=True)
+    scan = (lib[rng.integers(0, 160, 96)] + 0.35 * rng.standard_normal((96, 256))).astype(np.float32)
+    scan /= np.linalg.norm(scan, axis=1, keepdims=True)
+    best_match = rng.integers(0, 160, 96)
+    pos_n = int(0.1 * 160)
+    stat = ref_ret.scan2cad_retrieval_eval(scan, lib, best_match, table, pos_n)
+    from scipy.spatial.distance import cdist
+
+    d = cdist(scan, lib)
+    rank = np.argsort(d, 1)
+    # make sure the fixture has no exact distance ties among the first pos_n+1 ranks
+    srt = np.sort(d, 1)
+    assert (np.diff(srt[:, : pos_n + 2], axis=1) > 0).all()
+    np.savez_compressed(f"{OUT}/retrieval_kat.npz", scan=scan, lib=lib, best_match=best_match,
+                        table=table, pos_n=pos_n, precision=stat["precision"],
+                        top1_error=stat["top1_error"], top1_predict=np.array(stat["top1_predict"]),
+                        gt=np.array(stat["gt"]), rank_top=rank[:, : pos_n], dist_top=srt[:, : pos_n])
+    print("retrieval: precision", stat["precision"], "top1_error", stat["top1_error"])
+
+
+def make_real_clouds():
+    base = f"{REF}/docker/data/ShapeNetCore.v2.PC15k"
+    chair = sorted(os.listdir(f"{base}/03001627/test"))[0]
+    table = sorted(os.listdir(f"{base}/04379243/test"))[0]
+    np.savez_compressed(f"{OUT}/real_clouds.npz",
+                        chair=np.load(f"{base}/03001627/test/{chair}")[:10000].astype(np.float32),
+                        table=np.load(f"{base}/04379243/test/{table}")[:10000].astype(np.float32),
+                        names=np.array([chair, table]))
+
+
+if __name__ == "__main__":
+    make_eval_pose_kat()
+    make_aggregate_kat()
+    make_retrieval_kat()
+    make_real_clouds()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
