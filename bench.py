@@ -1,0 +1,294 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end queries/sec (embed + retrieve + register) of the CORSAIR hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): Scan2CAD-chair-sized synthetic evaluation -- catalog of 652
+CAD clouds, queries = posed re-samplings of catalog clouds, 10 000 points @ voxel 0.03, random-init
+ResUNetBN2C + embedding weights (the reference checkpoints / ScanNet data are not available).
+A step = one batch of 32 queries through: GPU voxelise -> sparse ResUNet forward -> global descriptor
+-> exact top-k against the catalog descriptors -> symmetry-aided registration against the top-1 CAD
+(feature 5-NN, part cut, K(+4) part hypotheses, batched RANSAC 100 000 x ransac_n 10, Chamfer).
+The raw query clouds and the embedded catalog are resident in HBM before the timed region.
+
+One process per GPU (torch.distributed / RCCL): the catalog is embedded in shards and all-gathered
+once (setup, reported as catalog_embed_s), queries are sharded with a fixed per-GPU count ("weak").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_PEAK_TFLOPS = 157.3   # MI355X f32: matrix (v_mfma_f32_32x32x2_f32) == vector peak (MI355X_MICROARCH.md)
+F64_PEAK_TFLOPS = 78.6
+BATCH = 32
+N_CATALOG = 652
+N_QUERY_POOL = 993
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="queries in the CPU baseline sample")
+    ap.add_argument("--catalog", type=int, default=N_CATALOG)
+    return ap.parse_args()
+
+
+def all_gather_sets(dist, torch, eset, world):
+    """All-gather an EmbeddedSet whose per-rank sizes differ (pad to the maximum).  This is the one
+    exchange of the path: RCCL all-gather of descriptors (+ per-voxel features of the catalog so any
+    rank can register against any CAD) over xGMI."""
+    from corsair_amd.harness import EmbeddedSet, concat_sets
+
+    dev = eset.F.device
+    n_rows = torch.tensor([eset.F.shape[0], len(eset)], device=dev, dtype=torch.int64)
+    sizes = [torch.zeros_like(n_rows) for _ in range(world)]
+    dist.all_gather(sizes, n_rows)
+    sizes = torch.stack(sizes).cpu().numpy()
+    max_rows, max_n = int(sizes[:, 0].max()), int(sizes[:, 1].max())
+
+    def gather(t, rows, width, dtype):
+        pad = torch.zeros((rows, width), device=dev, dtype=dtype)
+        pad[: t.shape[0]] = t.reshape(t.shape[0], width)
+        out = torch.empty((world * rows, width), device=dev, dtype=dtype)
+        dist.all_gather_into_tensor(out, pad)
+        return out.reshape(world, rows, width)
+
+    F = gather(eset.F, max_rows, 16, torch.float32)
+    O = gather(eset.origin, max_rows, 3, torch.float32)
+    D = gather(eset.desc, max_n, eset.desc.shape[1], torch.float32)
+    off = torch.tensor(eset.offsets, device=dev, dtype=torch.int64)
+    offp = gather(off[:, None], max_n + 1, 1, torch.int64)
+    sets = []
+    for r in range(world):
+        rows, n = int(sizes[r, 0]), int(sizes[r, 1])
+        sets.append(EmbeddedSet(F[r, :rows], O[r, :rows], offp[r, : n + 1, 0].cpu().tolist(), D[r, :n]))
+    return sets
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    from corsair_amd import _lib, harness, synth
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = harness.Config()
+    sd, emb = synth.make_state_dicts(cfg.random_seed)
+    pipe = harness.Pipeline(sd, emb, device=dev, config=cfg)
+
+    # ---- setup: catalog (sharded embed + all-gather) and this rank's query clouds -------------------
+    C = args.catalog
+    data = harness.SyntheticScan2CAD(n_catalog=C, n_points=cfg.n_points)
+    my_cat = list(range(rank, C, world))
+    n_q = (args.warmup + args.steps) * BATCH
+    q_ids = [(rank * n_q + i) % N_QUERY_POOL for i in range(n_q)]
+    t0 = time.time()
+    cat_clouds = [synth.make_cloud(c, 15000)[: cfg.n_points] for c in my_cat]
+    torch.cuda.synchronize()
+    t1 = time.time()
+    cat_local = pipe.embed_clouds(cat_clouds)
+    torch.cuda.synchronize()
+    if world > 1:
+        shards = all_gather_sets(dist, torch, cat_local, world)
+        # interleaved sharding: catalog id c lives at shard c % world, position c // world
+        order = np.argsort(np.concatenate([np.arange(r, C, world) for r in range(world)]), kind="stable")
+        catalog = harness.concat_sets(shards).gather(order)
+    else:
+        catalog = cat_local
+    torch.cuda.synchronize()
+    catalog_embed_s = time.time() - t1
+    sym = np.ones(C, np.int32)
+    sym[::326] = 4
+
+    q_clouds, q_T, q_cad = [], [], []
+    for q in q_ids:
+        cad = q % C
+        T = synth.random_pose(q, max_trans=0.0)
+        pc = synth.make_cloud(cad, 15000)[15000 - cfg.n_points:]
+        q_clouds.append(synth.apply_pose(pc, T))
+        q_T.append(T)
+        q_cad.append(cad)
+    q_dev, q_off = [], []
+    for b in range(args.warmup + args.steps):
+        chunk = q_clouds[b * BATCH:(b + 1) * BATCH]
+        q_dev.append(torch.from_numpy(np.concatenate(chunk, 0)).to(dev))
+        q_off.append(np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist())
+
+    results = []
+
+    def step(b):
+        qs = pipe.embed_batch(q_dev[b], q_off[b])
+        top = pipe.retrieve(qs.desc, catalog.desc, 1)[:, 0].cpu().numpy()
+        cads = catalog.gather(top)
+        ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
+        # force_gate: with random-init weights the part-cut acceptance gate (tuned to trained
+        # features; sym_ransac_success is True for 993/993 queries in the reference's caches) never
+        # passes, which would drop the K symmetric hypotheses -- 2/3 of the registration work -- from
+        # the timed region.  The bench accepts the best-balanced anchor so every query runs
+        # 1 + K (+4) RANSACs like the reference workload.  Parity tests use the real gate.
+        res = pipe.register(qs, cads, sym[top], anchor_ids=ids, force_gate=True)
+        results.append((b, top, res.T_best.cpu().numpy(), res.T_ransac.cpu().numpy(),
+                        res.cd_best.cpu().numpy(), res.ok, res.iters.cpu().numpy(), res.n_problems))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    log("setup done: catalog %d clouds embedded in %.2fs, %d query batches resident" %
+        (C, catalog_embed_s, len(q_dev)))
+    for b in range(args.warmup):
+        step(b)
+    log("warmup done")
+    results.clear()
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    barrier()
+    t_start = time.time()
+    for b in range(args.warmup, args.warmup + args.steps):
+        step(b)
+    barrier()
+    elapsed = time.time() - t_start
+    _lib.prof_enable(False)
+    log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- accuracy of the timed queries (outside the timed region) ---------------------------------------
+    t_l, r_l, hits, iters_all, nprob = [], [], 0, [], 0
+    for b, top, Tb, Tr, cdb, ok, iters, n_problems in results:
+        for i in range(BATCH):
+            qi = b * BATCH + i
+            t, r = harness.eval_pose(Tb[i], q_T[qi], np.eye(4), int(sym[top[i]]))
+            t_l.append(t)
+            r_l.append(r)
+            hits += int(top[i] == q_cad[qi])
+        iters_all.append(iters)
+        nprob += n_problems
+    agg = harness.aggregate(r_l, t_l)
+    iters_all = np.concatenate(iters_all)
+
+    if rank == 0:
+        fam = {}
+        for name in ("conv", "ransac_eval", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap"):
+            ms, n, units = _lib.prof_get(name)
+            fam[name] = {"ms": ms, "launches": n, "flop": units}
+        dom = max(("conv", "ransac_eval", "knn", "chamfer"), key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        peak = F64_PEAK_TFLOPS if dom in ("knn", "chamfer") else F32_PEAK_TFLOPS
+        achieved = (d["flop"] / max(d["launches"], 1)) / (max(d["ms"], 1e-9) / max(d["launches"], 1) * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_eval",
+                                                  "knn": "k_knn_feat", "chamfer": "k_chamfer"}[dom],
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
+                    "launches": d["launches"],
+                    "note": "f32 matrix peak == f32 vector peak on gfx950 (157.3 TF); see DESIGN.md"}
+        total_q = args.steps * BATCH * world
+        out = {
+            "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD chair",
+            "value": total_q / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single-MI355X Scan2CAD chair eval shape (C=%d catalog, "
+                                   "32 queries/step, 10k pts @ voxel 0.03, ResUNetBN2C+embedding random init, "
+                                   "top-1 retrieval, sym_pose RANSAC 100000x10)" % C,
+                       "queries_per_step": BATCH, "catalog": C, "catalog_embed_s": catalog_embed_s,
+                       "parallelism": "dp%d" % world,
+                       "ransac_problems_per_query": nprob / (args.steps * BATCH),
+                       "ransac_mean_iters": float(iters_all.mean()),
+                       "top1_hit_rate": hits / (args.steps * BATCH),
+                       "rre_mean_deg": agg["rre_mean_deg"], "rre_15": agg["rre_15"]},
+            "roofline": roofline,
+            "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg, sd, emb, catalog, sym, q_clouds, q_ids)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cfg, sd, emb, catalog, sym, q_clouds, q_ids):
+    """The CPU oracle (kind "port": the build's restatement of the reference CPU path, OpenMP over
+    independent rows / registrations) timed on a bounded sample of the same workload: the first
+    `cpu_sample` queries of the first timed step -- embed, retrieve (against the same catalog
+    descriptors) and register against the top-1 CAD."""
+    from corsair_amd import registration as R
+    from oracle import native, post, resunet as oref, sparse as osp
+
+    native.load()
+    n = args.cpu_sample
+    first = args.warmup * BATCH
+    clouds = q_clouds[first:first + n]
+    cat_desc = catalog.desc.cpu().numpy()
+    cat_F = catalog.F.cpu().numpy()
+    cat_X = catalog.origin.cpu().numpy()
+    off = catalog.offsets
+    t0 = time.time()
+    grids, origins = [], []
+    for pc in clouds:
+        xyz, grid, _ = osp.quantize_cloud(pc, cfg.voxel_size)
+        grids.append(grid)
+        origins.append(xyz)
+    coords = osp.sparse_collate(grids)
+    feats = np.ones((coords.shape[0], 1), np.float32)
+    out, feat8, maps = oref.resunet_forward(sd, coords, feats)
+    desc = oref.embedding_forward(emb, feat8, maps["c8"][:, 0], n)
+    t_embed = time.time() - t0
+    rank_, _ = post.retrieval_rank(desc, cat_desc)
+    top = rank_[:, 0]
+    t_ret = time.time() - t0 - t_embed
+    qoff = np.concatenate([[0], np.cumsum([len(g) for g in grids])])
+    for i in range(n):
+        F0, x0 = out[qoff[i]:qoff[i + 1]], origins[i]
+        c = int(top[i])
+        F1, x1 = cat_F[off[c]:off[c + 1]], cat_X[off[c]:off[c + 1]]
+        gq = first + i
+        a0 = R.draw_anchors(len(F0), 100, 2 * gq)
+        a1 = R.draw_anchors(len(F1), 100, 2 * gq + 1)
+        post.sym_pose(F0, x0, F1, x1, int(sym[c]), cfg.k_nn, cfg.max_corr, 0, a0, a1,
+                      cfg.ransac_max_iter, cfg.ransac_confidence, force_gate=True)
+    total = time.time() - t0
+    return {"value": n / total, "unit": "queries/s", "cores": native.num_threads(), "kind": "port",
+            "sample": "%d queries of the first timed step: oracle embed %.2fs + retrieve %.3fs + sym_pose %.2fs"
+                      % (n, t_embed, t_ret, total - t_embed - t_ret)}
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,7 @@ def _declare(lib):
         "cs_prof_enable": (None, [c_int]),
         "cs_prof_reset": (None, []),
         "cs_prof_get": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),
+        "cs_prof_get_units": (c_int, [c_char_p, POINTER(c_double)]),
         "cs_pool_trim": (None, []),
     }
     for name, (res, args) in sigs.items():
@@ -138,4 +139,6 @@ def prof_get(name):
     ms = c_double(0.0)
     n = c_int64(0)
     check(load().cs_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n)))
-    return ms.value, n.value
+    units = c_double(0.0)
+    check(load().cs_prof_get_units(name.encode(), ctypes.byref(units)))
+    return ms.value, n.value, units.value

@@ -72,7 +72,8 @@ struct ProfScope {
   int id;
   hipStream_t stream;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  ProfScope(const char* name, hipStream_t s);
+  // units: algorithmic work of the bracketed launch (FLOP for conv / ransac_eval / knn / ...)
+  ProfScope(const char* name, hipStream_t s, double units = 0.0);
   ~ProfScope();
 };
 

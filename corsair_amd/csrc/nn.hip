@@ -376,8 +376,10 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   PoolBuf<KnnWork> dwork;
   int rc = upload(dwork, work, s);
   if (rc) return rc;
+  double knn_flop = 0.0;
+  for (const KnnWork& w : work) knn_flop += 3.0 * (double)w.qn * (double)w.tn * (double)dim;
   {
-    ProfScope prof("knn", s);
+    ProfScope prof("knn", s, knn_flop);
     dim3 grid((unsigned)work.size());
     if (dim == 16)
       hipLaunchKernelGGL((k_knn_feat<16>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
@@ -466,8 +468,10 @@ int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tg
   if (!rc) rc = upload(dslot, slot_begin, s);
   if (!rc) rc = upload(dcount, src_count, s);
   if (rc) return rc;
+  double ch_flop = 0.0;
+  for (const ChamferWork& w : work) ch_flop += 8.0 * (double)w.sn * (double)w.tn;
   {
-    ProfScope prof("chamfer", s);
+    ProfScope prof("chamfer", s, ch_flop);
     if (!work.empty())
       hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
                          d_tgt, d_T, partial.p);

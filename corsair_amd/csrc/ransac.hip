@@ -398,8 +398,17 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                                     sizeof(unsigned long long) * b, n_prob, s));
     }
     CS_HIP_CHECK(hipMemsetAsync(n_active.p, 0, sizeof(int), s));
+    // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
+    // (transform 18 + squared distance 8 + compare/accumulate)
+    double eval_flop = 0.0;
+    for (int p = 0; p < n_prob; ++p) {
+      if (hp[p].done) continue;
+      int nh = hp[p].est_k - it0;
+      if (nh > b) nh = b;
+      if (nh > 0) eval_flop += 30.0 * (double)nh * (double)hp[p].m;
+    }
     {
-      ProfScope prof("ransac_eval", s);
+      ProfScope prof("ransac_eval", s, eval_flop);
       hipLaunchKernelGGL(k_ransac_eval, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
                          dim3(256), 0, s, probs.p, pack.p, hyp.p, it0, b, bmax, splits, thr2,
                          scale, res_cnt.p, res_err.p);
@@ -410,6 +419,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     CS_LAUNCH_CHECK();
     int h_active = 0;
     CS_HIP_CHECK(hipMemcpyAsync(&h_active, n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    // the per-problem state (est_k, done) comes back with the activity counter: it sizes the next
+    // chunk's work accounting and costs one small copy behind a synchronisation we need anyway
+    CS_HIP_CHECK(hipMemcpyAsync(hp.data(), probs.p, sizeof(RansacProb) * n_prob,
+                                hipMemcpyDeviceToHost, s));
     CS_HIP_CHECK(hipStreamSynchronize(s));
     it0 += b;
     if (h_active == 0) break;

@@ -103,6 +103,7 @@ struct ProfPending {
 static std::vector<ProfPending> g_pending[kNumProf];
 static double g_prof_ms[kNumProf] = {0};
 static int64_t g_prof_n[kNumProf] = {0};
+static double g_prof_units[kNumProf] = {0};
 
 static int prof_id(const char* name) {
   for (int i = 0; i < kNumProf; ++i)
@@ -110,10 +111,11 @@ static int prof_id(const char* name) {
   return -1;
 }
 
-ProfScope::ProfScope(const char* name, hipStream_t s) : id(-1), stream(s) {
+ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), stream(s) {
   if (!g_prof_on) return;
   id = prof_id(name);
   if (id < 0) return;
+  g_prof_units[id] += units;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     id = -1;
     return;
@@ -171,6 +173,7 @@ void cs_prof_reset(void) {
     cs::prof_drain(i);
     cs::g_prof_ms[i] = 0;
     cs::g_prof_n[i] = 0;
+    cs::g_prof_units[i] = 0;
   }
 }
 
@@ -183,6 +186,16 @@ int cs_prof_get(const char* name, double* total_ms, int64_t* launches) {
   cs::prof_drain(id);
   if (total_ms) *total_ms = cs::g_prof_ms[id];
   if (launches) *launches = cs::g_prof_n[id];
+  return CS_OK;
+}
+
+int cs_prof_get_units(const char* name, double* units) {
+  int id = cs::prof_id(name);
+  if (id < 0) {
+    cs::set_error("unknown profile family '%s'", name);
+    return CS_ERR_INVALID;
+  }
+  if (units) *units = cs::g_prof_units[id];
   return CS_OK;
 }
 

@@ -47,13 +47,19 @@ def draw_anchors(n, n_anchor, counter):
     return gen.choice(n, n_anchor, replace=False).astype(np.int32)
 
 
-def gate_and_order(centers, counts, min_cdist, max_err, n, K):
+def gate_and_order(centers, counts, min_cdist, max_err, n, K, force=False):
     """Acceptance gate + centre ordering of symmetric_cut4 (utils/symmetry.py:232-257) for one cloud.
     centers [A,4,3], counts [A,4], min_cdist/max_err [A] (NumPy).  Returns [4,3] centres ordered
     [0, nearest, farthest, middle] (K=4) or None when no anchor passes the gate."""
     ratios = counts[:, :K].astype(np.float64) / float(n)
     std = np.sqrt(np.var(ratios, axis=1))
     valid = (min_cdist > 0.15) & (0.15 > max_err) & (std < 100)
+    if force:
+        # bench-only: accept the best-balanced anchor whatever the gate says.  The thresholds are
+        # tuned to trained features (the reference's caches report sym_ransac_success for every
+        # query); with random-init weights they never pass and 2/3 of the registration work would
+        # silently disappear from the timed region.
+        valid = np.isfinite(max_err) & (min_cdist > 0)
     if not valid.any():
         return None
     a = int(np.argmin(np.where(valid, std, np.inf)))
@@ -80,7 +86,7 @@ def part_configs(K, pos_sym):
 
 def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_corr=0.20, seed=0,
                    anchor_ids=None, n_anchor=100, max_iter=100000, confidence=0.999,
-                   use_symmetry=True):
+                   use_symmetry=True, force_gate=False):
     """baseF f32 [N0,16], xyz0 f32 [N0,3] (query voxels of all pairs, segment p = off0[p]:off0[p+1]);
     posF/xyz1/off1 likewise for the CAD side; pos_syms: symmetry label per pair.
     anchor_ids[p] = (counter0, counter1) seeds the anchor draw of pair p (default (2p, 2p+1))."""
@@ -125,8 +131,8 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             c0, cnt0, mcd0, mer0 = fit(baseF, xyz0, off0, anc0)
             c1, cnt1, mcd1, mer1 = fit(posF, xyz1, off1, anc1)
             for p in cand:
-                g0 = gate_and_order(c0[p], cnt0[p], mcd0[p], mer0[p], n0[p], Ks[p])
-                g1 = gate_and_order(c1[p], cnt1[p], mcd1[p], mer1[p], n1[p], Ks[p])
+                g0 = gate_and_order(c0[p], cnt0[p], mcd0[p], mer0[p], n0[p], Ks[p], force_gate)
+                g1 = gate_and_order(c1[p], cnt1[p], mcd1[p], mer1[p], n1[p], Ks[p], force_gate)
                 if g0 is not None and g1 is not None:
                     sel0[p], sel1[p] = g0, g1
                     ok[p] = True

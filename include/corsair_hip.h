@@ -211,6 +211,8 @@ int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, cons
 void cs_prof_enable(int on);
 void cs_prof_reset(void);
 int cs_prof_get(const char* name, double* total_ms, int64_t* launches);
+/* algorithmic work (FLOP) the bracketed launches of the family performed since the last reset */
+int cs_prof_get_units(const char* name, double* units);
 
 /* Return all cached scratch memory to the HIP runtime. */
 void cs_pool_trim(void);

@@ -15,9 +15,14 @@
  * Build: gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp -shared -fPIC (oracle/native.py).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* Threads used by the OpenMP loops (independent rows / problems only: results never depend on it). */
+void oc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int oc_get_threads(void) { return omp_get_max_threads(); }
 
 /* ------------------------------------------------------------------------------------------
  * Sparse convolution forward + fused epilogue.
@@ -352,6 +357,8 @@ void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, in
     for (int a = 0; a < 3; ++a) t[a] = (float)td[a];
     int cnt = 0;
     uint64_t err = 0;
+    /* integer sums: the thread split does not change the result */
+#pragma omp parallel for reduction(+ : cnt, err) schedule(static) if (m >= 8192)
     for (int64_t i = 0; i < m; ++i) {
       const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
       const float px = fmaf(R[0], sx, fmaf(R[1], sy, fmaf(R[2], sz, t[0])));

@@ -29,6 +29,10 @@ def build(force=False):
     return LIB
 
 
+def num_threads():
+    return int(load().oc_get_threads())
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -63,6 +67,14 @@ def load():
                                       c_uint64, vp, vp, vp, vp]
         lib.oc_symcut_labels.argtypes = [vp, c_int, c_int, vp, vp]
         lib.oc_voxel_index.argtypes = [vp, c_int64, c_float, vp]
+        lib.oc_set_threads.argtypes = [c_int]
+        lib.oc_get_threads.restype = c_int
+        # never oversubscribe: the GPU box exposes many more logical CPUs than its share
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        lib.oc_set_threads(max(1, min(16, avail)))
         _lib = lib
     return _lib
 
