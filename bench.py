@@ -204,7 +204,7 @@ def main():
         d = fam[dom]
         peak = F64_PEAK_TFLOPS if dom in ("knn", "chamfer") else F32_PEAK_TFLOPS
         achieved = (d["flop"] / max(d["launches"], 1)) / (max(d["ms"], 1e-9) / max(d["launches"], 1) * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_eval",
+        roofline = {"bound": "mfma", "kernel": {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_count",
                                                   "knn": "k_knn_feat", "chamfer": "k_chamfer"}[dom],
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),

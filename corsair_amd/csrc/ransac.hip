@@ -5,16 +5,25 @@
 // Semantics: Open3D's loop as executed by ONE thread (iteration order = index order), with the
 // global Mersenne twister replaced by a counter-based generator so that iteration i of every
 // problem is reproducible anywhere.  Iterations are processed in growing chunks; within a chunk
-//   k_ransac_hyp   one lane per hypothesis: sample ransac_n pairs, closed-form rigid fit
-//                  (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f32
-//   k_ransac_eval  one lane per hypothesis, correspondences streamed through the scalar cache
-//                  (wave-uniform s_load), 9 fma + 3 sub + 3 fma + compare per pair in f32;
-//                  inlier count (int) and fixed-point squared error (u64) are exact integers, so
-//                  any split of the correspondence range across waves gives identical sums
-//   k_ransac_scan  per problem, replays the chunk in iteration order: best-so-far update and
-//                  the early-exit bound est_k, exactly as the sequential loop would
-// The correspondence set of a problem (M x 32 B ~ 0.7 MB at eval size) is L2 resident, so the
-// evaluation is VALU-bound: ~20 f32 VALU ops per (hypothesis, pair).
+//   k_ransac_hyp    one lane per hypothesis: sample ransac_n pairs, closed-form rigid fit
+//                   (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f32
+//   k_ransac_count  the hot kernel.  A wave owns 32 hypotheses; the residual d = R s + t - q of a
+//                   32-correspondence x 32-hypothesis tile is TWO v_mfma_f32_32x32x2_f32 per
+//                   coordinate (K = [sx, sy | sz, 1] against [r0, r1 | r2, t]) whose accumulator
+//                   INPUT is -q read straight from LDS: the matrix pipe does the 21 transform and
+//                   residual flops of every (hypothesis, pair), the VALU only the squared norm,
+//                   compare and count (5 instructions per pair) and runs concurrently.
+//                   f32 MFMA is an ordered fma chain, so the inlier test is bit-identical to the
+//                   scalar oracle:  d = fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))).
+//                   Correspondences are staged per 256 through LDS as structure-of-arrays.
+//   k_ransac_scan1  one wave per problem replays the chunk in iteration order (prefix max of the
+//                   inlier counts -> early-exit bound est_k -> stop position) and lists the
+//                   hypotheses that tie for the best count
+//   k_ransac_err    fixed-point squared error (exact integer sums) of those few candidates only
+//   k_ransac_scan2  best = max count, then min error, then first -- the final state of the
+//                   sequential rule "better = more inliers, or equal inliers and smaller rmse"
+// Inlier counts and fixed-point errors are integers, so any split of the correspondence range across
+// workgroups gives identical sums.
 #include <math.h>
 
 #include <vector>
@@ -22,6 +31,9 @@
 #include "common.h"
 
 namespace cs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 struct RansacProb {
   int64_t off;
@@ -32,6 +44,9 @@ struct RansacProb {
   unsigned long long best_err;
   int32_t done;
   int32_t iters;
+  // per-chunk scratch written by scan1, read by err / scan2
+  int32_t n_cand;
+  int32_t chunk_max;
   float best_T[12];
 };
 
@@ -47,12 +62,17 @@ __host__ __device__ static inline uint32_t rng_index(uint64_t seed, uint64_t itr
   return (uint32_t)(((rng_u64(seed, itr, j) >> 32) * (uint64_t)m) >> 32);
 }
 
+// structure-of-arrays copy of the correspondences: pk[c * total + i], c = sx,sy,sz,qx,qy,qz
 __global__ void k_ransac_pack(const float* __restrict__ src, const float* __restrict__ tgt,
-                              int64_t n, float4* __restrict__ pack) {
+                              int64_t n, float* __restrict__ pk) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  pack[2 * i + 0] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
-  pack[2 * i + 1] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], 0.f);
+  pk[0 * n + i] = src[3 * i + 0];
+  pk[1 * n + i] = src[3 * i + 1];
+  pk[2 * n + i] = src[3 * i + 2];
+  pk[3 * n + i] = tgt[3 * i + 0];
+  pk[4 * n + i] = tgt[3 * i + 1];
+  pk[5 * n + i] = tgt[3 * i + 2];
 }
 
 // Cyclic Jacobi on a symmetric 4x4 (fixed 8 sweeps), eigenvectors in v (columns).
@@ -100,9 +120,10 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
   }
 }
 
-// hyp layout: [prob][12][bmax] (structure of arrays so the evaluating lanes read coalesced)
+// hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
 __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict__ probs,
-                                                    const float4* __restrict__ pack, int it0,
+                                                    const float* __restrict__ src,
+                                                    const float* __restrict__ tgt, int it0,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed, float* __restrict__ hyp) {
   const int p = blockIdx.y;
@@ -112,31 +133,30 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
   const int itr = it0 + h;
   if (pr.done || itr >= pr.est_k) return;
   const uint32_t m = (uint32_t)pr.m;
-  // centroids
   double cs_[3] = {0, 0, 0}, ct_[3] = {0, 0, 0};
   for (int j = 0; j < ransac_n; ++j) {
     const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    const float4 s = pack[2 * i], t = pack[2 * i + 1];
-    cs_[0] += (double)s.x;
-    cs_[1] += (double)s.y;
-    cs_[2] += (double)s.z;
-    ct_[0] += (double)t.x;
-    ct_[1] += (double)t.y;
-    ct_[2] += (double)t.z;
+    // sampled rows are read from the caller's [M,3] arrays (12-byte rows: one or two lines each)
+    cs_[0] += (double)src[3 * i + 0];
+    cs_[1] += (double)src[3 * i + 1];
+    cs_[2] += (double)src[3 * i + 2];
+    ct_[0] += (double)tgt[3 * i + 0];
+    ct_[1] += (double)tgt[3 * i + 1];
+    ct_[2] += (double)tgt[3 * i + 2];
   }
-  const double inv_n = (double)ransac_n;
+  const double dn = (double)ransac_n;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    cs_[a] = cs_[a] / inv_n;
-    ct_[a] = ct_[a] / inv_n;
+    cs_[a] = cs_[a] / dn;
+    ct_[a] = ct_[a] / dn;
   }
-  // cross-covariance S[a][b] = sum (s_a - cs_a)(t_b - ct_b)
   double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int j = 0; j < ransac_n; ++j) {
     const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    const float4 s = pack[2 * i], t = pack[2 * i + 1];
-    const double ds[3] = {(double)s.x - cs_[0], (double)s.y - cs_[1], (double)s.z - cs_[2]};
-    const double dt[3] = {(double)t.x - ct_[0], (double)t.y - ct_[1], (double)t.z - ct_[2]};
+    const double ds[3] = {(double)src[3 * i + 0] - cs_[0], (double)src[3 * i + 1] - cs_[1],
+                          (double)src[3 * i + 2] - cs_[2]};
+    const double dt[3] = {(double)tgt[3 * i + 0] - ct_[0], (double)tgt[3 * i + 1] - ct_[1],
+                          (double)tgt[3 * i + 2] - ct_[2]};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -199,95 +219,312 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
   }
 }
 
-// grid: x = hypothesis tile (256) * splits, y = problem
-__global__ __launch_bounds__(256) void k_ransac_eval(const RansacProb* __restrict__ probs,
-                                                     const float4* __restrict__ pack,
-                                                     const float* __restrict__ hyp, int it0,
-                                                     int bcount, int bmax, int splits, float thr2,
-                                                     float scale, int32_t* __restrict__ res_cnt,
-                                                     unsigned long long* __restrict__ res_err) {
+// ------------------------------------------------------------------------------------------------
+// Inlier counting on the matrix pipe.
+// grid: x = (hypothesis tile of 128) * splits + split, y = problem; block = 4 waves x 32 hypotheses.
+// MFMA operand maps (v_mfma_f32_32x32x2_f32): lane l supplies A[row l&31][k = l>>5] and
+// B[k = l>>5][col l&31]; D[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31] in register r.
+// rows = correspondences, cols = hypotheses: a lane owns ONE hypothesis and, per tile, 16
+// correspondences.  The accumulator INPUT is loaded with -target straight from LDS, so the MFMA
+// chain delivers the residual d = R s + t - q itself and the VALU is left with 3 fma-class ops, one
+// compare and one add-with-carry per pair (the kernel is VALU-issue bound otherwise: a wave64 f32
+// VALU op occupies the SIMD for 4 cycles on gfx950, measured with SQ_ACTIVE_INST_VALU).
+// ------------------------------------------------------------------------------------------------
+#ifndef RC_CHUNK_SZ
+#define RC_CHUNK_SZ 256
+#endif
+#ifndef RC_PACKED
+#define RC_PACKED 0
+#endif
+constexpr int RC_CHUNK = RC_CHUNK_SZ;     // correspondences per LDS stage (multiple of 256)
+constexpr int RC_STG = RC_CHUNK / 256;    // staged rows per thread
+constexpr int RC_TILES = RC_CHUNK / 32;   // 32-correspondence MFMA tiles per stage
+
+__global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
+                                                      const float* __restrict__ pk, int64_t total,
+                                                      const float* __restrict__ hyp, int it0,
+                                                      int bcount, int bmax, int splits, float thr2,
+                                                      int32_t* __restrict__ res_cnt) {
+  // [buf][c][j]: c = 0..2 source xyz, c = 3..5 NEGATED target xyz (the MFMA accumulator input)
+  __shared__ __attribute__((aligned(16))) float lds[2][6][RC_CHUNK];
   const int p = blockIdx.y;
   const int tile = blockIdx.x / splits;
   const int split = blockIdx.x - tile * splits;
-  const int h = tile * 256 + threadIdx.x;
   const RansacProb pr = probs[p];
   if (pr.done) return;
-  if (it0 + tile * 256 >= pr.est_k) return;  // whole tile beyond the bound
-  const bool valid = h < bcount && it0 + h < pr.est_k;
-  const int hh = valid ? h : 0;
-  const float* hp = hyp + ((int64_t)p * 12) * bmax + hh;
-  const float r00 = hp[0 * (int64_t)bmax], r01 = hp[1 * (int64_t)bmax],
-              r02 = hp[2 * (int64_t)bmax], tx = hp[3 * (int64_t)bmax];
-  const float r10 = hp[4 * (int64_t)bmax], r11 = hp[5 * (int64_t)bmax],
-              r12 = hp[6 * (int64_t)bmax], ty = hp[7 * (int64_t)bmax];
-  const float r20 = hp[8 * (int64_t)bmax], r21 = hp[9 * (int64_t)bmax],
-              r22 = hp[10 * (int64_t)bmax], tz = hp[11 * (int64_t)bmax];
-  const int per = (pr.m + splits - 1) / splits;
+  if (it0 + tile * 128 >= pr.est_k || tile * 128 >= bcount) return;  // whole block beyond the bound
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction
+  const int half = lane >> 5;
+  const int col = lane & 31;
+  const int h0 = tile * 128 + wave * 32;                  // first hypothesis of this wave
+  const bool wave_live = h0 < bcount && it0 + h0 < pr.est_k;
+  // B operands of this lane: hypothesis column h0 + col, k-slot = half
+  float b1[3], b2[3];
+  {
+    const int hh = min(h0 + col, bmax - 1);
+    const float* hp = hyp + ((int64_t)p * 12) * bmax + hh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      b1[c] = hp[(int64_t)(4 * c + half) * bmax];       // r_c0 | r_c1
+      b2[c] = hp[(int64_t)(4 * c + 2 + half) * bmax];   // r_c2 | t_c
+    }
+  }
+  const int per = ((pr.m + splits - 1) / splits + RC_CHUNK - 1) / RC_CHUNK * RC_CHUNK;
   const int beg = split * per;
   const int end = min(pr.m, beg + per);
-  const float4* __restrict__ pk = pack + 2 * pr.off;
-  int cnt = 0;
-  unsigned long long err = 0;
-#pragma unroll 4
-  for (int i = beg; i < end; ++i) {
-    const float4 s = pk[2 * i];
-    const float4 q = pk[2 * i + 1];
-    const float px = __fmaf_rn(r00, s.x, __fmaf_rn(r01, s.y, __fmaf_rn(r02, s.z, tx)));
-    const float py = __fmaf_rn(r10, s.x, __fmaf_rn(r11, s.y, __fmaf_rn(r12, s.z, ty)));
-    const float pz = __fmaf_rn(r20, s.x, __fmaf_rn(r21, s.y, __fmaf_rn(r22, s.z, tz)));
-    const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-    const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-    const bool in = d2 < thr2;
-    cnt += in ? 1 : 0;
-    err += in ? (unsigned long long)(uint32_t)(d2 * scale) : 0ULL;
-  }
-  if (valid) {
-    if (splits == 1) {
-      res_cnt[(int64_t)p * bmax + h] = cnt;
-      res_err[(int64_t)p * bmax + h] = err;
-    } else {
-      atomicAdd(&res_cnt[(int64_t)p * bmax + h], cnt);
-      atomicAdd(&res_err[(int64_t)p * bmax + h], err);
+  int cnt = 0;  // inliers of hypothesis (h0 + col) among the rows this half-wave owns
+
+  // staging: 6 arrays x 512 floats = 12 floats per thread, loaded to registers at the top of a
+  // stage and written to the other LDS buffer after the stage's compute (loads overlap the MFMAs).
+  // Rows past the range become far-away targets (never inliers).
+  float stg[6 * RC_STG];
+  auto stage_load = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < RC_STG; ++u) {
+      const int i = base + tid + 256 * u;
+      const int64_t g = pr.off + (i < end ? i : 0);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) stg[6 * u + c] = pk[(int64_t)c * total + g];  // no use yet
     }
+  };
+  auto stage_store = [&](int b, int base) {
+#pragma unroll
+    for (int u = 0; u < RC_STG; ++u) {
+      const bool ok = base + tid + 256 * u < end;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        float v = stg[6 * u + c];
+        if (c >= 3) v = -v;
+        lds[b][c][tid + 256 * u] = ok ? v : (c >= 3 ? -1.0e30f : 0.0f);
+      }
+    }
+  };
+
+  if (beg < end) {
+    stage_load(beg);
+    stage_store(0, beg);
+  }
+  int buf = 0;
+  for (int base = beg; base < end; base += RC_CHUNK) {
+    __syncthreads();
+    const bool more = base + RC_CHUNK < end;
+    if (more) stage_load(base + RC_CHUNK);
+    if (wave_live) {
+#pragma unroll 1
+      for (int t = 0; t < RC_TILES; ++t) {
+        const int j0 = t * 32;
+        const float s1 = lds[buf][half][j0 + col];                   // sx | sy
+        const float s2 = half ? 1.0f : lds[buf][2][j0 + col];        // sz | 1
+        // accumulator input = -target of the 16 rows this lane owns: rows 4*half + 8g + (0..3)
+        f32x16 dx, dy, dz;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 vx = *reinterpret_cast<const float4*>(&lds[buf][3][j0 + 4 * half + 8 * g]);
+          const float4 vy = *reinterpret_cast<const float4*>(&lds[buf][4][j0 + 4 * half + 8 * g]);
+          const float4 vz = *reinterpret_cast<const float4*>(&lds[buf][5][j0 + 4 * half + 8 * g]);
+          dx[4 * g + 0] = vx.x; dx[4 * g + 1] = vx.y; dx[4 * g + 2] = vx.z; dx[4 * g + 3] = vx.w;
+          dy[4 * g + 0] = vy.x; dy[4 * g + 1] = vy.y; dy[4 * g + 2] = vy.z; dy[4 * g + 3] = vy.w;
+          dz[4 * g + 0] = vz.x; dz[4 * g + 1] = vz.y; dz[4 * g + 2] = vz.z; dz[4 * g + 3] = vz.w;
+        }
+        // d = ((( -q + r0 sx) + r1 sy) + r2 sz) + t, one rounding per step, on the matrix pipe
+        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[0], dx, 0, 0, 0);
+        dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[1], dy, 0, 0, 0);
+        dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[2], dz, 0, 0, 0);
+        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[0], dx, 0, 0, 0);
+        dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[1], dy, 0, 0, 0);
+        dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[2], dz, 0, 0, 0);
+#if RC_PACKED
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x2 = {dx[r], dx[r + 1]}, y2 = {dy[r], dy[r + 1]}, z2 = {dz[r], dz[r + 1]};
+          const f32x2 d2 = __builtin_elementwise_fma(z2, z2, __builtin_elementwise_fma(y2, y2, x2 * x2));
+          cnt += d2[0] < thr2 ? 1 : 0;
+          cnt += d2[1] < thr2 ? 1 : 0;
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d2 = __fmaf_rn(dz[r], dz[r], __fmaf_rn(dy[r], dy[r], dx[r] * dx[r]));
+          cnt += d2 < thr2 ? 1 : 0;
+        }
+#endif
+      }
+    }
+    if (more) stage_store(buf ^ 1, base + RC_CHUNK);
+    buf ^= 1;
+  }
+  if (!wave_live) return;
+  cnt += __shfl_xor(cnt, 32);  // the two half-waves own disjoint correspondence rows
+  const int h = h0 + col;
+  if (half == 0 && h < bcount && it0 + h < pr.est_k) {
+    if (splits == 1)
+      res_cnt[(int64_t)p * bmax + h] = cnt;
+    else
+      atomicAdd(&res_cnt[(int64_t)p * bmax + h], cnt);
   }
 }
 
-__global__ void k_ransac_scan(RansacProb* probs, int n_prob, const float* __restrict__ hyp,
-                              const int32_t* __restrict__ res_cnt,
-                              const unsigned long long* __restrict__ res_err, int it0, int bcount,
-                              int bmax, int ransac_n, int max_iter, double log_1mc,
-                              int* n_active) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_prob) return;
+// est_k implied by a best inlier count c (Open3D: log(1 - confidence) / log(1 - ratio^n))
+__device__ __forceinline__ int est_bound(int c, int m, int ransac_n, double log_1mc, int est_k0) {
+  const double ratio = fmin(1.0, (double)c / (double)m);
+  double pw = 1.0;
+  for (int j = 0; j < ransac_n; ++j) pw = pw * ratio;
+  const double den = log(1.0 - pw);
+  if (den < 0.0) {  // den == 0: (inliers/M)^n below 2^-53 -> no finite bound
+    const double est = log_1mc / den;
+    if (est < (double)est_k0) return (int)ceil(est);
+  }
+  return est_k0;
+}
+
+// One wave per problem: sequential-semantics replay of the chunk from the inlier counts alone.
+__global__ __launch_bounds__(64) void k_ransac_scan1(RansacProb* probs, int n_prob,
+                                                     const int32_t* __restrict__ res_cnt, int it0,
+                                                     int bcount, int bmax, int ransac_n,
+                                                     int max_iter, double log_1mc,
+                                                     int32_t* __restrict__ cand, int* n_active) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
   RansacProb pr = probs[p];
   if (pr.done) return;
-  int h = 0;
-  for (; h < bcount; ++h) {
-    const int itr = it0 + h;
-    if (itr >= pr.est_k) break;
-    const int cnt = res_cnt[(int64_t)p * bmax + h];
-    const unsigned long long err = res_err[(int64_t)p * bmax + h];
-    if (cnt > pr.best_cnt || (cnt == pr.best_cnt && cnt > 0 && err < pr.best_err)) {
-      pr.best_cnt = cnt;
-      pr.best_err = err;
-      pr.best_itr = itr;
-      for (int c = 0; c < 12; ++c) pr.best_T[c] = hyp[((int64_t)p * 12 + c) * bmax + h];
-      const double ratio = fmin(1.0, (double)cnt / (double)pr.m);
-      double pw = 1.0;
-      for (int j = 0; j < ransac_n; ++j) pw = pw * ratio;
-      const double den = log(1.0 - pw);
-      if (den < 0.0) {  // den == 0: (inliers/M)^n below 2^-53, no finite bound
-        const double est = log_1mc / den;
-        if (est < (double)pr.est_k) pr.est_k = (int)ceil(est);
+  const int32_t* cnt = res_cnt + (int64_t)p * bmax;
+  const int seg = (bcount + 63) / 64;
+  const int s0 = lane * seg, s1 = min(bcount, s0 + seg);
+  // 1. exclusive prefix max of the counts over lanes, seeded with the carried best
+  int lmax = 0;
+  for (int h = s0; h < s1; ++h)
+    if (it0 + h < pr.est_k) lmax = max(lmax, cnt[h]);
+  int incl = lmax;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl = max(incl, o);
+  }
+  int pre = __shfl_up(incl, 1);
+  if (lane == 0) pre = 0;
+  pre = max(pre, pr.best_cnt);
+  // 2. first position where the loop of the reference would stop
+  int stop = 0x7fffffff;
+  {
+    int cur = pre;
+    int ek = cur > pr.best_cnt ? est_bound(cur, pr.m, ransac_n, log_1mc, pr.est_k) : pr.est_k;
+    for (int h = s0; h < s1; ++h) {
+      if (it0 + h >= ek) {
+        stop = h;
+        break;
+      }
+      const int c = cnt[h];
+      if (c > cur) {
+        cur = c;
+        ek = est_bound(cur, pr.m, ransac_n, log_1mc, pr.est_k);
       }
     }
   }
-  const int consumed = it0 + h;
-  if (consumed >= pr.est_k || consumed >= max_iter) {
-    pr.done = 1;
-    pr.iters = consumed < max_iter ? consumed : max_iter;
-  } else {
-    atomicAdd(n_active, 1);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) stop = min(stop, __shfl_xor(stop, off));
+  if (stop > bcount) stop = bcount;
+  // 3. best count over the evaluated prefix, new bound
+  int cmax = 0;
+  for (int h = s0; h < min(s1, stop); ++h) cmax = max(cmax, cnt[h]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+  int new_ek = pr.est_k;
+  if (cmax > pr.best_cnt) new_ek = est_bound(cmax, pr.m, ransac_n, log_1mc, pr.est_k);
+  // 4. candidates: evaluated hypotheses that tie for the best count (ascending order)
+  int ncand = 0;
+  if (cmax > 0 && cmax >= pr.best_cnt) {
+    int mine = 0;
+    for (int h = s0; h < min(s1, stop); ++h) mine += cnt[h] == cmax;
+    int incl2 = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl2, off);
+      if (lane >= off) incl2 += o;
+    }
+    int pos = incl2 - mine;
+    ncand = __shfl(incl2, 63);
+    for (int h = s0; h < min(s1, stop); ++h)
+      if (cnt[h] == cmax) cand[(int64_t)p * bmax + pos++] = h;
+  }
+  if (lane == 0) {
+    const int consumed = it0 + stop;
+    pr.est_k = new_ek;
+    pr.n_cand = ncand;
+    pr.chunk_max = cmax;
+    if (consumed >= pr.est_k || consumed >= max_iter) {
+      pr.done = 1;
+      pr.iters = consumed < max_iter ? consumed : max_iter;
+    } else {
+      atomicAdd(n_active, 1);
+    }
+    // best_* are updated by scan2; keep everything else
+    probs[p] = pr;
+  }
+}
+
+// Fixed-point squared error of the candidate hypotheses: grid (slots, problems).
+__global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict__ probs,
+                                                    const float* __restrict__ pk, int64_t total,
+                                                    const float* __restrict__ hyp, int bmax,
+                                                    const int32_t* __restrict__ cand, float thr2,
+                                                    float scale,
+                                                    unsigned long long* __restrict__ cand_err) {
+  __shared__ unsigned long long red[256];
+  const int p = blockIdx.y;
+  const RansacProb pr = probs[p];
+  const int tid = threadIdx.x;
+  for (int c = blockIdx.x; c < pr.n_cand; c += gridDim.x) {
+    const int h = cand[(int64_t)p * bmax + c];
+    const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
+    float R[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
+    unsigned long long err = 0;
+    for (int i = tid; i < pr.m; i += 256) {
+      const int64_t g = pr.off + i;
+      const float sx = pk[0 * total + g], sy = pk[1 * total + g], sz = pk[2 * total + g];
+      // same chain as the MFMA pair: fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q))))
+      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -pk[3 * total + g]))) + R[3];
+      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -pk[4 * total + g]))) + R[7];
+      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -pk[5 * total + g]))) + R[11];
+      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+      if (d2 < thr2) err += (unsigned long long)(uint32_t)(d2 * scale);
+    }
+    red[tid] = err;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) cand_err[(int64_t)p * bmax + c] = red[0];
+    __syncthreads();
+  }
+}
+
+__global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const float* __restrict__ hyp,
+                               const int32_t* __restrict__ cand,
+                               const unsigned long long* __restrict__ cand_err, int it0, int bmax) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_prob) return;
+  RansacProb pr = probs[p];
+  if (pr.n_cand <= 0) return;
+  bool changed = false;
+  int best_h = -1;
+  for (int c = 0; c < pr.n_cand; ++c) {
+    const unsigned long long e = cand_err[(int64_t)p * bmax + c];
+    if (pr.chunk_max > pr.best_cnt || e < pr.best_err) {
+      pr.best_cnt = pr.chunk_max;
+      pr.best_err = e;
+      best_h = cand[(int64_t)p * bmax + c];
+      changed = true;
+    }
+  }
+  pr.n_cand = 0;
+  if (changed) {
+    pr.best_itr = it0 + best_h;
+    for (int c = 0; c < 12; ++c) pr.best_T[c] = hyp[((int64_t)p * 12 + c) * bmax + best_h];
   }
   probs[p] = pr;
 }
@@ -346,28 +583,26 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     pr.off = h_off[p];
     pr.m = (int32_t)m;
     pr.est_k = max_iter;
-    pr.best_cnt = 0;
     pr.best_itr = -1;
-    pr.best_err = 0;
     // Open3D returns the default (identity) result when there are fewer pairs than ransac_n
     pr.done = m < ransac_n ? 1 : 0;
-    pr.iters = 0;
     if (m > m_max) m_max = (int)m;
   }
   const int bmax = 4096;
+  const int64_t tot1 = total ? total : 1;
   PoolBuf<RansacProb> probs(n_prob);
-  PoolBuf<float4> pack((size_t)(total ? total : 1) * 2);
+  PoolBuf<float> pk((size_t)tot1 * 6);
   PoolBuf<float> hyp((size_t)n_prob * 12 * bmax);
-  PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax);
-  PoolBuf<unsigned long long> res_err((size_t)n_prob * bmax);
+  PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax), cand((size_t)n_prob * bmax);
+  PoolBuf<unsigned long long> cand_err((size_t)n_prob * bmax);
   PoolBuf<int> n_active(1);
-  CS_REQUIRE(probs.p && pack.p && hyp.p && res_cnt.p && res_err.p && n_active.p, CS_ERR_HIP,
-             "cs_ransac_batch: scratch allocation failed");
+  CS_REQUIRE(probs.p && pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p && n_active.p,
+             CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   CS_HIP_CHECK(hipMemcpyAsync(probs.p, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
     hipLaunchKernelGGL(k_ransac_pack, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
-                       d_src, d_tgt, total, pack.p);
+                       d_src, d_tgt, total, pk.p);
     CS_LAUNCH_CHECK();
   }
   // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
@@ -381,22 +616,21 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   while (it0 < max_iter) {
     int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
     if (b > max_iter - it0) b = max_iter - it0;
-    const int tiles = (b + 255) / 256;
-    int splits = (int)(8192 / ((int64_t)n_prob * tiles * 4 > 0 ? (int64_t)n_prob * tiles * 4 : 1));
+    const int tiles = (b + 127) / 128;
+    // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
+    // chunk is small (integer partial sums combine exactly)
+    int splits = (int)(4096 / ((int64_t)n_prob * tiles > 0 ? (int64_t)n_prob * tiles : 1));
     if (splits < 1) splits = 1;
     if (splits > 16) splits = 16;
-    if (m_max < 2048) splits = 1;
+    while (splits > 1 && m_max / splits < 4 * RC_CHUNK) --splits;
     {
       ProfScope prof("ransac_hyp", s);
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)tiles, (unsigned)n_prob), dim3(256), 0, s,
-                         probs.p, pack.p, it0, b, bmax, ransac_n, seed, hyp.p);
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
+                         dim3(256), 0, s, probs.p, d_src, d_tgt, it0, b, bmax, ransac_n, seed, hyp.p);
     }
-    if (splits > 1) {  // partial sums of the splits are combined with integer atomics
+    if (splits > 1)  // partial counts of the splits are combined with integer atomics
       CS_HIP_CHECK(hipMemset2DAsync(res_cnt.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                     n_prob, s));
-      CS_HIP_CHECK(hipMemset2DAsync(res_err.p, sizeof(unsigned long long) * bmax, 0,
-                                    sizeof(unsigned long long) * b, n_prob, s));
-    }
     CS_HIP_CHECK(hipMemsetAsync(n_active.p, 0, sizeof(int), s));
     // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
     // (transform 18 + squared distance 8 + compare/accumulate)
@@ -409,13 +643,16 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     }
     {
       ProfScope prof("ransac_eval", s, eval_flop);
-      hipLaunchKernelGGL(k_ransac_eval, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                         dim3(256), 0, s, probs.p, pack.p, hyp.p, it0, b, bmax, splits, thr2,
-                         scale, res_cnt.p, res_err.p);
+      hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
+                         dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                         res_cnt.p);
     }
-    hipLaunchKernelGGL(k_ransac_scan, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       probs.p, n_prob, hyp.p, res_cnt.p, res_err.p, it0, b, bmax, ransac_n,
-                       max_iter, log_1mc, n_active.p);
+    hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(64), 0, s, probs.p, n_prob,
+                       res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, n_active.p);
+    hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, probs.p, pk.p,
+                       tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
+    hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
+                       probs.p, n_prob, hyp.p, cand.p, cand_err.p, it0, bmax);
     CS_LAUNCH_CHECK();
     int h_active = 0;
     CS_HIP_CHECK(hipMemcpyAsync(&h_active, n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -361,10 +361,12 @@ void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, in
 #pragma omp parallel for reduction(+ : cnt, err) schedule(static) if (m >= 8192)
     for (int64_t i = 0; i < m; ++i) {
       const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-      const float px = fmaf(R[0], sx, fmaf(R[1], sy, fmaf(R[2], sz, t[0])));
-      const float py = fmaf(R[3], sx, fmaf(R[4], sy, fmaf(R[5], sz, t[1])));
-      const float pz = fmaf(R[6], sx, fmaf(R[7], sy, fmaf(R[8], sz, t[2])));
-      const float dx = px - tgt[3 * i], dy = py - tgt[3 * i + 1], dz = pz - tgt[3 * i + 2];
+      /* canonical order of the residual d = R s + t - q: start from -q, add the x, y, z terms,
+       * then the translation, one rounding per step
+       * (= fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))), the chain an f32 MFMA evaluates) */
+      const float dx = fmaf(R[2], sz, fmaf(R[1], sy, fmaf(R[0], sx, -tgt[3 * i]))) + t[0];
+      const float dy = fmaf(R[5], sz, fmaf(R[4], sy, fmaf(R[3], sx, -tgt[3 * i + 1]))) + t[1];
+      const float dz = fmaf(R[8], sz, fmaf(R[7], sy, fmaf(R[6], sx, -tgt[3 * i + 2]))) + t[2];
       const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
       if (d2 < thr2) {
         cnt += 1;
