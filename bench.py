@@ -43,38 +43,6 @@ def parse():
     return ap.parse_args()
 
 
-def all_gather_sets(dist, torch, eset, world):
-    """All-gather an EmbeddedSet whose per-rank sizes differ (pad to the maximum).  This is the one
-    exchange of the path: RCCL all-gather of descriptors (+ per-voxel features of the catalog so any
-    rank can register against any CAD) over xGMI."""
-    from corsair_amd.harness import EmbeddedSet, concat_sets
-
-    dev = eset.F.device
-    n_rows = torch.tensor([eset.F.shape[0], len(eset)], device=dev, dtype=torch.int64)
-    sizes = [torch.zeros_like(n_rows) for _ in range(world)]
-    dist.all_gather(sizes, n_rows)
-    sizes = torch.stack(sizes).cpu().numpy()
-    max_rows, max_n = int(sizes[:, 0].max()), int(sizes[:, 1].max())
-
-    def gather(t, rows, width, dtype):
-        pad = torch.zeros((rows, width), device=dev, dtype=dtype)
-        pad[: t.shape[0]] = t.reshape(t.shape[0], width)
-        out = torch.empty((world * rows, width), device=dev, dtype=dtype)
-        dist.all_gather_into_tensor(out, pad)
-        return out.reshape(world, rows, width)
-
-    F = gather(eset.F, max_rows, 16, torch.float32)
-    O = gather(eset.origin, max_rows, 3, torch.float32)
-    D = gather(eset.desc, max_n, eset.desc.shape[1], torch.float32)
-    off = torch.tensor(eset.offsets, device=dev, dtype=torch.int64)
-    offp = gather(off[:, None], max_n + 1, 1, torch.int64)
-    sets = []
-    for r in range(world):
-        rows, n = int(sizes[r, 0]), int(sizes[r, 1])
-        sets.append(EmbeddedSet(F[r, :rows], O[r, :rows], offp[r, : n + 1, 0].cpu().tolist(), D[r, :n]))
-    return sets
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -82,7 +50,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
-    from corsair_amd import _lib, harness, synth
+    from corsair_amd import _lib, harness, sharding, synth
 
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -99,8 +67,7 @@ def main():
 
     # ---- setup: catalog (sharded embed + all-gather) and this rank's query clouds -------------------
     C = args.catalog
-    data = harness.SyntheticScan2CAD(n_catalog=C, n_points=cfg.n_points)
-    my_cat = list(range(rank, C, world))
+    my_cat = sharding.shard_ids(C, rank, world)
     n_q = (args.warmup + args.steps) * BATCH
     q_ids = [(rank * n_q + i) % N_QUERY_POOL for i in range(n_q)]
     t0 = time.time()
@@ -109,13 +76,8 @@ def main():
     t1 = time.time()
     cat_local = pipe.embed_clouds(cat_clouds)
     torch.cuda.synchronize()
-    if world > 1:
-        shards = all_gather_sets(dist, torch, cat_local, world)
-        # interleaved sharding: catalog id c lives at shard c % world, position c // world
-        order = np.argsort(np.concatenate([np.arange(r, C, world) for r in range(world)]), kind="stable")
-        catalog = harness.concat_sets(shards).gather(order)
-    else:
-        catalog = cat_local
+    # the one exchange of the path: RCCL all-gather of the embedded catalog shards over xGMI
+    catalog = sharding.gather_catalog(dist, cat_local, C, world)
     torch.cuda.synchronize()
     catalog_embed_s = time.time() - t1
     sym = np.ones(C, np.int32)

@@ -1,0 +1,78 @@
+"""Multi-process sharding logic on CPU (gloo, world_size 2): interleaved catalog shards, the
+all-gather of the embedded catalog and the reassembly into catalog order -- the N > 1 path of
+bench.py (RCCL on the GPU node)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_set(ids):
+    """EmbeddedSet whose contents encode the item id (item c has 3 + c % 4 voxels)."""
+    from corsair_amd.harness import EmbeddedSet
+
+    F, O, off, D = [], [], [0], []
+    for c in ids:
+        n = 3 + c % 4
+        F.append(torch.full((n, 16), float(c)) + torch.arange(n)[:, None] * 0.01)
+        O.append(torch.full((n, 3), -float(c)))
+        off.append(off[-1] + n)
+        D.append(torch.full((1, 256), float(c)))
+    if not ids:
+        return EmbeddedSet(torch.zeros((0, 16)), torch.zeros((0, 3)), [0], torch.zeros((0, 256)))
+    return EmbeddedSet(torch.cat(F), torch.cat(O), off, torch.cat(D))
+
+
+def _worker(rank, world, port, n_items, out_dir):
+    import torch.distributed as dist
+
+    from corsair_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = sharding.shard_ids(n_items, rank, world)
+        full = sharding.gather_catalog(dist, _fake_set(mine), n_items, world)
+        want = _fake_set(list(range(n_items)))
+        ok = (full.offsets == want.offsets and torch.equal(full.F, want.F)
+              and torch.equal(full.origin, want.origin) and torch.equal(full.desc, want.desc))
+        # query sharding: every rank owns a disjoint, equally sized slice (weak scaling)
+        sub = full.gather([n_items - 1, 0, 0])
+        ok = ok and sub.offsets == [0, 3 + (n_items - 1) % 4, 6 + (n_items - 1) % 4, 9 + (n_items - 1) % 4]
+        ok = ok and float(sub.desc[0, 0]) == n_items - 1
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8])
+def test_catalog_all_gather_world2(tmp_path, n_items):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def test_shard_ids_cover_everything():
+    from corsair_amd import sharding
+
+    for n in (0, 1, 5, 652):
+        for world in (1, 2, 4, 8):
+            ids = [i for r in range(world) for i in sharding.shard_ids(n, r, world)]
+            assert sorted(ids) == list(range(n))
+            order = sharding.global_order(n, world)
+            assert [ids[j] for j in order] == list(range(n))
