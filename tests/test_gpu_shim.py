@@ -1,0 +1,118 @@
+"""The MinkowskiEngine-compatible operator surface (drop-in boundary) on the GPU:
+reference-style model code built from ME modules == fused engine == CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torch_sd(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def test_model_code_on_shim_matches_engine_and_oracle(gpu, oracle_native):
+    sys.path.insert(0, os.path.join(ROOT, "shim"))
+    import MinkowskiEngine as ME  # noqa: the shim package
+
+    from corsair_amd import engine, synth
+    from corsair_amd.model import load_model
+    from corsair_amd.model import fc
+    from oracle import resunet as oref
+
+    assert ME.__version__ >= "0.5.4"  # string compare at model/resunet.py:55
+    coords, feats, _, offsets = make_batch([11, 12], n_points=4000)
+    sd, emb = synth.make_state_dicts(31)
+
+    Model = load_model("ResUNetBN2C")
+    model = Model(1, 16, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=3, D=3).to(gpu)
+    head = fc.conv1_max_embedding(1024, 512, 256).to(gpu)
+    # reference checkpoints are loaded exactly like this (evaluation.py:195-201)
+    model.load_state_dict(_torch_sd(sd))
+    head.load_state_dict(_torch_sd(emb))
+    model.eval()
+    head.eval()
+    with torch.no_grad():
+        x = ME.SparseTensor(torch.from_numpy(feats).to(gpu), torch.from_numpy(coords).to(gpu))
+        out, feat = model(x)
+        g = torch.nn.functional.normalize(head(feat), dim=1)
+    # row order of the input is preserved (evaluation.py:227-229 masks origins with out.C[:,0] == i)
+    assert np.array_equal(out.C.cpu().numpy(), coords)
+
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    e_out, e_feat, maps = eng.forward(torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu))
+    e_g = eng.embed(e_feat, maps, 2)
+    assert torch.equal(out.F, e_out) and torch.equal(feat.F, e_feat)   # op-by-op == fused
+    assert torch.allclose(g, e_g, atol=2e-6)                           # dense head: torch Linear vs MFMA
+    want_out, want_feat, _ = oref.resunet_forward(sd, coords, feats)
+    assert np.array_equal(out.F.cpu().numpy(), want_out)
+    assert np.array_equal(feat.F.cpu().numpy(), want_feat)
+    # state-dict names are the reference's: 129 tensors + embedding
+    names = set(model.state_dict().keys())
+    assert names == set(sd.keys()) and len(names) == 129
+    assert set(head.state_dict().keys()) == set(emb.keys())
+
+
+def test_shim_sparse_tensor_semantics(gpu):
+    sys.path.insert(0, os.path.join(ROOT, "shim"))
+    import MinkowskiEngine as ME
+    import MinkowskiEngine.MinkowskiFunctional as MEF
+
+    coords, feats, _, _ = make_batch([13], n_points=1500)
+    c = torch.from_numpy(coords).to(gpu)
+    x = ME.SparseTensor(torch.randn(len(coords), 8, device=gpu), c)
+    y = ME.SparseTensor(torch.randn(len(coords), 8, device=gpu), coordinate_map_key=x.coordinate_map_key,
+                        coordinate_manager=x.coordinate_manager)
+    z = ME.cat(x, y)
+    assert z.F.shape[1] == 16 and torch.equal(z.F[:, :8], x.F)
+    want = x.F + y.F
+    x += y
+    assert torch.equal(x.F, want)
+    assert (MEF.relu(x).F >= 0).all()
+    conv = ME.MinkowskiConvolution(8, 8, kernel_size=3, stride=2, dimension=3).to(gpu)
+    up = ME.MinkowskiConvolutionTranspose(8, 4, kernel_size=3, stride=2, dimension=3).to(gpu)
+    with torch.no_grad():
+        d = conv(x)
+        u = up(d)
+    assert d.tensor_stride == [2, 2, 2] and u.tensor_stride == [1, 1, 1]
+    assert u.coordinate_map_key == x.coordinate_map_key and u.F.shape == (len(coords), 4)
+    # mismatched maps / duplicate coordinates raise like ME
+    with pytest.raises(RuntimeError):
+        ME.cat(x, d)
+    with pytest.raises(RuntimeError):
+        ME.SparseTensor(torch.ones(2, 1, device=gpu), torch.zeros((2, 4), dtype=torch.int32, device=gpu))
+    # ME.utils runs on the host (DataLoader workers) and keeps the first point per voxel
+    pts = np.random.default_rng(0).uniform(-1, 1, (500, 3))
+    idx = ME.utils.sparse_quantize(np.floor(pts / 0.2), return_index=True, return_maps_only=True)
+    from oracle import sparse
+
+    assert np.array_equal(idx, sparse.sparse_quantize(np.floor(pts / 0.2)))
+    bc, bf = ME.utils.sparse_collate([np.floor(pts[idx] / 0.2)], [np.ones((len(idx), 1))])
+    assert bc.dtype == torch.int32 and bc.shape == (len(idx), 4) and (bc[:, 0] == 0).all()
+
+
+def test_gpu_voxelize_matches_sparse_quantize(gpu):
+    """cs_voxelize == ME.utils.sparse_quantize + sparse_collate semantics."""
+    from corsair_amd import backend as B, synth
+    from oracle import sparse
+
+    clouds = [synth.make_cloud(i, 15000)[:n] for i, n in ((40, 10000), (41, 3000), (42, 1))]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).tolist()
+    xyz = torch.from_numpy(np.concatenate(clouds)).to(gpu)
+    for voxel in (0.03, 0.02):
+        keep, grid, out_off = B.voxelize(xyz, off, voxel)
+        keep, grid = keep.cpu().numpy(), grid.cpu().numpy()
+        grids, keeps = [], []
+        for b, c in enumerate(clouds):
+            _, g, k = sparse.quantize_cloud(c, voxel)
+            grids.append(g)
+            keeps.append(k + off[b])
+        assert np.array_equal(keep, np.concatenate(keeps))
+        assert np.array_equal(grid, sparse.sparse_collate(grids))
+        assert out_off == np.concatenate([[0], np.cumsum([len(g) for g in grids])]).tolist()
