@@ -234,7 +234,10 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
 #define RC_CHUNK_SZ 256
 #endif
 #ifndef RC_PACKED
-#define RC_PACKED 0
+#define RC_PACKED 0   // packed f32 (v_pk_*) buys nothing here: measured equal within noise
+#endif
+#ifndef RC_SETPRIO
+#define RC_SETPRIO 1  // +2-3 %: waves about to issue MFMAs win arbitration over VALU-phase waves
 #endif
 constexpr int RC_CHUNK = RC_CHUNK_SZ;     // correspondences per LDS stage (multiple of 256)
 constexpr int RC_STG = RC_CHUNK / 256;    // staged rows per thread
@@ -329,12 +332,18 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
           dz[4 * g + 0] = vz.x; dz[4 * g + 1] = vz.y; dz[4 * g + 2] = vz.z; dz[4 * g + 3] = vz.w;
         }
         // d = ((( -q + r0 sx) + r1 sy) + r2 sz) + t, one rounding per step, on the matrix pipe
+#if RC_SETPRIO
+        __builtin_amdgcn_s_setprio(1);  // the wave that is ready to feed the matrix pipe goes first
+#endif
         dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[0], dx, 0, 0, 0);
         dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[1], dy, 0, 0, 0);
         dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[2], dz, 0, 0, 0);
         dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[0], dx, 0, 0, 0);
         dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[1], dy, 0, 0, 0);
         dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[2], dz, 0, 0, 0);
+#if RC_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if RC_PACKED
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -588,7 +597,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     pr.done = m < ransac_n ? 1 : 0;
     if (m > m_max) m_max = (int)m;
   }
-  const int bmax = 4096;
+  // Largest chunk of iterations per round.  One workgroup = 128 hypotheses x all pairs of a problem
+  // (~100 us), 1536 workgroups are resident: chunks of 16384 give >= 8 "waves" of workgroups for a
+  // 32-query batch, so the partially filled last wave costs ~10 % instead of ~33 % at 4096.
+  const int bmax = 16384;
   const int64_t tot1 = total ? total : 1;
   PoolBuf<RansacProb> probs(n_prob);
   PoolBuf<float> pk((size_t)tot1 * 6);
