@@ -171,7 +171,17 @@ def main():
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
                     "launches": d["launches"],
+                    "flop_per_launch": d["flop"] / max(d["launches"], 1),
                     "note": "f32 matrix peak == f32 vector peak on gfx950 (157.3 TF); see DESIGN.md"}
+        # HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run of this same
+        # command (FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/)
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("kernel") == roofline["kernel"]:
+                roofline["traffic"] = tj["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tj["source"]
         total_q = args.steps * BATCH * world
         out = {
             "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD chair",
