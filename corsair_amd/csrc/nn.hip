@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
                                                   const int32_t* __restrict__ perm,
                                                   int32_t* __restrict__ out_idx,
                                                   double* __restrict__ out_dist) {
-  __shared__ float t_lds[KNN_TT * DIM];
+  // targets are converted to f64 once per tile (the inner loop is f64-VALU bound: one v_cvt less
+  // per dimension and pair)
+  __shared__ double t_lds[KNN_TT * DIM];
   __shared__ int32_t tl_lds[KNN_TT];
   const KnnWork wk = work[blockIdx.x];
   const int tid = threadIdx.x;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
   for (int tbase = 0; tbase < wk.tn; tbase += KNN_TT) {
     const int tcount = min(KNN_TT, wk.tn - tbase);
     __syncthreads();
-    for (int i = tid; i < tcount * DIM; i += 256) t_lds[i] = tf[(wk.t0 + tbase) * DIM + i];
+    for (int i = tid; i < tcount * DIM; i += 256) t_lds[i] = (double)tf[(wk.t0 + tbase) * DIM + i];
     if (use_labels)
       for (int i = tid; i < tcount; i += 256) tl_lds[i] = tlabel[wk.t0 + tbase + i];
     __syncthreads();
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
       double d = 0.0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        double diff = q[c] - (double)t_lds[j * DIM + c];
+        double diff = q[c] - t_lds[j * DIM + c];
         d = fma(diff, diff, d);
       }
       if (d < bd[KNN_MAXK - 1]) {

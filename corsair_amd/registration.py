@@ -148,20 +148,22 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
                     perms.append(cfg + [-3] * (8 - len(cfg)))
                     cfg_pair.append(p)
             perm_t = torch.tensor(perms, dtype=torch.int32, device=dev)
-            nn_cfg = B.knn_feat(baseF, off0, posF, off1, k, qseg=qseg, tseg=tseg, qlabel=lab0,
-                                tlabel=lab1, perm=perm_t)
             # stable partition of every query cloud by part label (split_corr concatenates the parts
-            # in order, rows in original order inside a part)
-            order = {}
-            for p in good:
-                order[p] = torch.sort(lab0[off0[p]:off0[p + 1]], stable=True).indices
+            # in order, rows in original order inside a part): one stable sort of (pair, label) keys.
+            # The labelled search runs on the partitioned rows, so a wave of 64 queries shares one
+            # label and skips the targets of the other parts wholesale.
+            seg_rows = torch.repeat_interleave(torch.arange(P, device=dev, dtype=torch.int64),
+                                               torch.tensor(n0, device=dev, dtype=torch.int64))
+            sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
+            nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
+                                qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
             row = 0
             for j, p in enumerate(cfg_pair):
-                idx = nn_cfg[row:row + n0[p]][order[p]]
+                idx = nn_cfg[row:row + n0[p]]          # rows already in (part, original row) order
                 row += n0[p]
                 if bool((idx < 0).any()):
                     continue  # a CAD part with fewer than k voxels: the reference cannot build it
-                prob_src.append((order[p] + off0[p]).repeat_interleave(k))
+                prob_src.append(sorted_rows[off0[p]:off0[p + 1]].repeat_interleave(k))
                 prob_tgt.append((idx.to(torch.int64) + off1[p]).reshape(-1))
                 prob_len.append(n0[p] * k)
                 prob_pair.append(p)
