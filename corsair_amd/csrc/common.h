@@ -114,6 +114,7 @@ struct cs_kernelmap {
   int64_t n_out = 0, n_in = 0;
   int kvol = 27;
   int transposed = 0;
-  int32_t* d_nbr = nullptr;  // [n_out, kvol]
+  int32_t* d_nbr = nullptr;      // [n_out, kvol]
+  int32_t* d_rowlist = nullptr;  // [n_out] output rows ordered by neighbour-presence mask (tiling order)
   int64_t num_pairs = -1;
 };

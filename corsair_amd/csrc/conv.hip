@@ -16,7 +16,10 @@
 //     reads for the MFMA A operand), the weight slab [32, TN] is staged next to it; the loads of
 //     chunk c+1 are issued before the MFMAs of chunk c.
 //   * the neighbour table of the tile ([TM,27] int32) is read once into LDS; offsets no row of
-//     the tile uses are skipped (exact: they would add zeros).
+//     the tile uses are skipped (exact: they would add zeros).  Tiles are formed over the kernel
+//     map's row list, which orders output rows by their 27-bit neighbour-presence mask, so the rows
+//     of a tile share most of their absent offsets (for transposed maps: the parity class, <= 8
+//     live offsets of 27) and the skip removes most of the zero work.
 //   * epilogue (BN affine / bias, residual add, ReLU) is applied to the accumulators and written
 //     with an arbitrary leading dimension so decoder outputs land directly in the concat buffer.
 #include "common.h"
@@ -39,8 +42,9 @@ __device__ __forceinline__ float epilogue(float v, int c, const float* __restric
 
 template <int WM, int WN, int NT>
 __global__ __launch_bounds__(256) void k_conv_mfma(
-    const int32_t* __restrict__ nbr, int kvol, int64_t n_in, int64_t n_out,
-    const float* __restrict__ in, int ld_in, int cin, const float* __restrict__ w, int cout,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist, int kvol, int64_t n_in,
+    int64_t n_out, const float* __restrict__ in, int ld_in, int cin, const float* __restrict__ w,
+    int cout,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out,
     int ld_out) {
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(
   __shared__ float A_lds[TM * APITCH];
   __shared__ float B_lds[KC * TN];
   __shared__ int32_t nbr_lds[TM * 27];
+  __shared__ int32_t orow_lds[TM];   // output row of tile slot r (rows are visited in rowlist order)
   __shared__ unsigned kmask_lds;
 
   const int tid = threadIdx.x;
@@ -74,7 +79,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(
       int r = i / kvol, k = i - r * kvol;
       int64_t o = row0 + r;
       int32_t v = -1;
-      if (o < n_out) v = nbr ? nbr[o * kvol + k] : (int32_t)o;
+      if (o < n_out) {
+        if (rowlist) o = rowlist[o];
+        v = nbr ? nbr[o * kvol + k] : (int32_t)o;
+        if (k == 0) orow_lds[r] = (int32_t)o;
+      } else if (k == 0) {
+        orow_lds[r] = -1;
+      }
       nbr_lds[r * 27 + k] = v;
       if (v >= 0) local_mask |= 1u << k;
     }
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      const int64_t o = row0 + r;
-      if (o >= n_out) continue;
+      const int64_t o = orow_lds[r];
+      if (o < 0) continue;
       const float* res_row = residual ? residual + o * ld_res : nullptr;
       out[o * ld_out + col] = epilogue(acc[t][i], col, scale, shift, res_row, relu);
     }
@@ -291,12 +302,14 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
              "cs_conv_fwd: too many rows");
   int kvol = 1;
   const int32_t* nbr = nullptr;
+  const int32_t* rowlist = nullptr;
   if (km) {
     CS_REQUIRE(km->n_out == n_out && km->n_in == n_in, CS_ERR_INVALID,
                "cs_conv_fwd: kernel map is for %lld -> %lld rows, tensors have %lld -> %lld",
                (long long)km->n_in, (long long)km->n_out, (long long)n_in, (long long)n_out);
     kvol = km->kvol;
     nbr = km->d_nbr;
+    rowlist = km->d_rowlist;
   } else {
     CS_REQUIRE(n_in == n_out, CS_ERR_INVALID, "cs_conv_fwd: 1x1 conv needs n_in == n_out");
   }
@@ -309,17 +322,17 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   if (mfma_ok) {
     if (cout % 128 == 0) {
       dim3 grid((unsigned)ceil_div(n_out, 64), (unsigned)(cout / 128));
-      hipLaunchKernelGGL((k_conv_mfma<2, 2, 2>), grid, dim3(256), 0, s, nbr, kvol, n_in, n_out,
+      hipLaunchKernelGGL((k_conv_mfma<2, 2, 2>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
                          d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
                          d_out, ld_out);
     } else if (cout > 32) {
       dim3 grid((unsigned)ceil_div(n_out, 64), (unsigned)ceil_div(cout, 64));
-      hipLaunchKernelGGL((k_conv_mfma<2, 2, 1>), grid, dim3(256), 0, s, nbr, kvol, n_in, n_out,
+      hipLaunchKernelGGL((k_conv_mfma<2, 2, 1>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
                          d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
                          d_out, ld_out);
     } else {
       dim3 grid((unsigned)ceil_div(n_out, 128), 1);
-      hipLaunchKernelGGL((k_conv_mfma<4, 1, 1>), grid, dim3(256), 0, s, nbr, kvol, n_in, n_out,
+      hipLaunchKernelGGL((k_conv_mfma<4, 1, 1>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
                          d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
                          d_out, ld_out);
     }

@@ -138,6 +138,17 @@ __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_ou
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
 }
 
+// 27-bit neighbour-presence mask of every output row + identity row ids (sorted by mask afterwards)
+__global__ void k_row_masks(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
+                            uint32_t* __restrict__ mask, int32_t* __restrict__ rows) {
+  int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  uint32_t m = 0;
+  for (int k = 0; k < kvol; ++k) m |= (nbr[o * kvol + k] >= 0 ? 1u : 0u) << k;
+  mask[o] = m;
+  rows[o] = (int32_t)o;
+}
+
 // export helpers: element t = k * n_out + o of the k-major view
 __global__ void k_export_flag(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
                               int32_t* flag) {
@@ -401,6 +412,33 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     return CS_ERR_HIP;
   }
   km->num_pairs = (int64_t)h_cnt;
+  // tiling order for the convolution kernels: rows sorted by presence mask (stable radix sort)
+  if (km->kvol == 27 && km->n_out > 0) {
+    const int64_t n = km->n_out;
+    km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
+    PoolBuf<uint32_t> mask(n), mask_sorted(n);
+    PoolBuf<int32_t> rows(n);
+    if (!km->d_rowlist || !mask.p || !mask_sorted.p || !rows.p) {
+      cs_kernelmap_free(km);
+      set_error("cs_kernelmap_build: row list allocation failed");
+      return CS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_row_masks, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, km->d_nbr, n,
+                       km->kvol, mask.p, rows.p);
+    size_t tmp_bytes = 0;
+    hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, mask.p, mask_sorted.p, rows.p,
+                                                       km->d_rowlist, (int)n, 0, 27, s);
+    PoolBuf<char> tmp(tmp_bytes);
+    if (e2 == hipSuccess && tmp.p)
+      e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, mask.p, mask_sorted.p, rows.p,
+                                              km->d_rowlist, (int)n, 0, 27, s);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+    if (e2 != hipSuccess || !tmp.p) {
+      cs_kernelmap_free(km);
+      set_error("cs_kernelmap_build: row sort failed: %s", hipGetErrorString(e2));
+      return CS_ERR_HIP;
+    }
+  }
   *km_out = km;
   return CS_OK;
 }
@@ -437,6 +475,7 @@ int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in,
 void cs_kernelmap_free(cs_kernelmap* km) {
   if (!km) return;
   pool_free(km->d_nbr);
+  pool_free(km->d_rowlist);
   delete km;
 }
 
