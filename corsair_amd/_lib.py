@@ -51,6 +51,8 @@ def _declare(lib):
                                 POINTER(c_int32), c_int, c_int, c_int, vp, vp, vp, vp, vp, vp]),
         "cs_chamfer_1dir": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), POINTER(c_int32),
                                     POINTER(c_int32), c_int, vp, vp, vp]),
+        "cs_hausdorff_1dir": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), POINTER(c_int32),
+                                      POINTER(c_int32), c_int, vp, vp, vp]),
         "cs_ransac_batch": (c_int, [vp, vp, POINTER(c_int64), c_int, c_float, c_int, c_int, c_double,
                                     c_uint64, vp, vp, vp, vp, vp]),
         "cs_symcut_fit": (c_int, [vp, c_int, vp, POINTER(c_int64), c_int, vp, c_int,

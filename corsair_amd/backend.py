@@ -269,6 +269,19 @@ def chamfer_1dir(src, soff, tgt, toff, src_seg, tgt_seg, T):
     return out
 
 
+def hausdorff_1dir(src, soff, tgt, toff, src_seg, tgt_seg, T):
+    """Batched directed Hausdorff distance (max over source points of the nearest-target distance)."""
+    src = _dev(src, torch.float32, "source").contiguous()
+    tgt = _dev(tgt, torch.float32, "target").contiguous()
+    T = _dev(T, torch.float32, "transforms").contiguous()
+    n_prob = len(src_seg)
+    out = torch.empty(n_prob, dtype=torch.float64, device=src.device)
+    check(_lib.load().cs_hausdorff_1dir(ptr(src), i64_array(soff), ptr(tgt), i64_array(toff),
+                                        i32_array(src_seg), i32_array(tgt_seg), n_prob, ptr(T), ptr(out),
+                                        stream_ptr()))
+    return out
+
+
 def ransac_batch(src, tgt, offsets, max_corr, ransac_n=10, max_iter=100000, confidence=0.999, seed=0):
     """Batched correspondence RANSAC.  Returns (T f32 [n,4,4], inliers int32, rmse f64, iters int32)."""
     src = _dev(src, torch.float32, "source correspondences").contiguous()

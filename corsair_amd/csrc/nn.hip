@@ -269,7 +269,7 @@ constexpr int CH_TT = 512;
 __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__ work,
                                                  const float* __restrict__ src,
                                                  const float* __restrict__ tgt,
-                                                 const float* __restrict__ T,
+                                                 const float* __restrict__ T, int reduce_max,
                                                  double* __restrict__ partial) {
   __shared__ float t_lds[CH_TT * 3];
   __shared__ double red[256];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__
   red[tid] = active ? sqrt(best) : 0.0;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) red[tid] += red[tid + off];
+    if (tid < off) red[tid] = reduce_max ? fmax(red[tid], red[tid + off]) : red[tid] + red[tid + off];
     __syncthreads();
   }
   if (tid == 0) partial[wk.slot] = red[0];
@@ -312,13 +312,17 @@ __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__
 
 __global__ void k_chamfer_finish(const double* __restrict__ partial,
                                  const int32_t* __restrict__ slot_begin,
-                                 const int64_t* __restrict__ src_count, int n_prob,
+                                 const int64_t* __restrict__ src_count, int n_prob, int reduce_max,
                                  double* __restrict__ out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_prob) return;
   double s = 0.0;
-  for (int i = slot_begin[p]; i < slot_begin[p + 1]; ++i) s += partial[i];
-  out[p] = src_count[p] > 0 ? s / (double)src_count[p] : NAN;
+  for (int i = slot_begin[p]; i < slot_begin[p + 1]; ++i)
+    s = reduce_max ? fmax(s, partial[i]) : s + partial[i];
+  if (reduce_max)
+    out[p] = src_count[p] > 0 ? s : NAN;
+  else
+    out[p] = src_count[p] > 0 ? s / (double)src_count[p] : NAN;
 }
 
 template <typename T>
@@ -431,9 +435,9 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   return CS_OK;
 }
 
-int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
-                    const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
-                    int n_prob, const float* d_T, double* d_out, void* stream) {
+static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                          const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                          int n_prob, const float* d_T, int reduce_max, double* d_out, void* stream) {
   CS_REQUIRE(d_src && d_tgt && h_soff && h_toff && h_src_seg && h_tgt_seg && d_T && d_out,
              CS_ERR_INVALID, "cs_chamfer_1dir: NULL argument");
   if (n_prob <= 0) return CS_OK;
@@ -476,13 +480,27 @@ int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tg
     ProfScope prof("chamfer", s, ch_flop);
     if (!work.empty())
       hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
-                         d_tgt, d_T, partial.p);
+                         d_tgt, d_T, reduce_max, partial.p);
     hipLaunchKernelGGL(k_chamfer_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       partial.p, dslot.p, dcount.p, n_prob, d_out);
+                       partial.p, dslot.p, dcount.p, n_prob, reduce_max, d_out);
     CS_LAUNCH_CHECK();
   }
   CS_HIP_CHECK(hipStreamSynchronize(s));
   return CS_OK;
+}
+
+int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                    const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                    int n_prob, const float* d_T, double* d_out, void* stream) {
+  return nn_dist_reduce(d_src, h_soff, d_tgt, h_toff, h_src_seg, h_tgt_seg, n_prob, d_T, 0, d_out,
+                        stream);
+}
+
+int cs_hausdorff_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                      const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                      int n_prob, const float* d_T, double* d_out, void* stream) {
+  return nn_dist_reduce(d_src, h_soff, d_tgt, h_toff, h_src_seg, h_tgt_seg, n_prob, d_T, 1, d_out,
+                        stream);
 }
 
 }  // extern "C"

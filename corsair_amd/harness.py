@@ -19,7 +19,6 @@ import torch
 from . import backend as B
 from . import engine as E
 from . import registration as R
-from .utils import retrieval as ret
 from .utils.eval_pose import eval_pose
 
 
@@ -72,7 +71,10 @@ class Pipeline:
     def embed_batch(self, xyz, offsets):
         """xyz f32 [n,3] device (concatenated raw clouds, already normalised), offsets host list.
         Returns an EmbeddedSet for the batch."""
-        keep, grid, out_off = B.voxelize(xyz, offsets, self.cfg.voxel_size)
+        return self.embed_batch_raw(xyz, offsets, self.cfg.voxel_size)
+
+    def embed_batch_raw(self, xyz, offsets, voxel_size):
+        keep, grid, out_off = B.voxelize(xyz, offsets, voxel_size)
         origin = xyz[keep]
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=xyz.device)
         out, feat8, maps = self.engine.forward(grid, feats)

@@ -163,6 +163,13 @@ int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tg
                     const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
                     int n_prob, const float* d_T, double* d_out, void* stream);
 
+/* Directed Hausdorff distance: same arguments, d_out[p] = MAX over source points of the distance to
+ * the nearest target point.  Replaces one direction of chamfer_max in the geometric symmetry test
+ * of evaluation-shapenet.py:122-155 (get_symmetry_label), SURVEY 8f rank 2. */
+int cs_hausdorff_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
+                      const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
+                      int n_prob, const float* d_T, double* d_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batched correspondence RANSAC.  Replaces registration_based_on_corr ->
  * o3d.pipelines.registration.registration_ransac_based_on_correspondence(src, tgt, corr,

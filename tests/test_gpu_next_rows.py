@@ -1,0 +1,118 @@
+"""SURVEY 8f 'next' rows on the GPU: geometric symmetry label + ShapeNet-style registration eval,
+pairwise Chamfer table, both against SciPy KD-tree restatements of the reference code."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ring_cloud(n_fold, n=3000, seed=0, jitter=0.0):
+    """Object with exact n_fold rotational symmetry about the y axis (one random blob, replicated)."""
+    from corsair_amd.synth import euler2mat
+
+    rng = np.random.default_rng(seed)
+    blob = rng.normal(0, 0.05, (n // n_fold, 3)) + np.array([0.6, 0.0, 0.1])
+    blob[:, 1] = rng.uniform(-0.4, 0.4, len(blob))
+    parts = [blob @ euler2mat(0, 2 * np.pi * i / n_fold, 0).T for i in range(n_fold)]
+    pc = np.concatenate(parts)
+    return pc + rng.normal(0, jitter, pc.shape) if jitter else pc
+
+
+def _ref_symmetry_label(pc, thr):
+    """evaluation-shapenet.py:122-155 with SciPy KD-trees (vectorised queries)."""
+    from scipy.spatial import KDTree
+
+    from corsair_amd.synth import euler2mat
+
+    tree = KDTree(pc)
+    for s in [12, 8, 6, 4, 3, 2, 1]:
+        ok = True
+        for i in range(1, s // 2 + 1):
+            rot = pc @ euler2mat(0, i * 2 * np.pi / s, 0).T
+            err = max(KDTree(rot).query(pc)[0].max(), tree.query(rot)[0].max())
+            if err > thr:
+                ok = False
+                break
+        if ok:
+            return s
+    return 0
+
+
+@pytest.mark.parametrize("n_fold", [1, 2, 3, 4, 6])
+def test_get_symmetry_label(gpu, n_fold):
+    from corsair_amd import shapenet_eval as S
+
+    pc = S.load_pc(_ring_cloud(n_fold, seed=n_fold))
+    want = _ref_symmetry_label(pc.astype(np.float32).astype(np.float64), 0.1)
+    got = S.get_symmetry_label(pc, 0.1)
+    assert got == want
+    if n_fold in (2, 3, 4, 6):
+        assert got % n_fold == 0 or got == n_fold
+
+
+def test_hausdorff_matches_kdtree(gpu):
+    from scipy.spatial import KDTree
+
+    from corsair_amd import shapenet_eval as S
+
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-1, 1, (1200, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (900, 3)).astype(np.float32)
+    want = max(KDTree(b).query(a.astype(np.float64))[0].max(), KDTree(a).query(b.astype(np.float64))[0].max())
+    assert S.chamfer_max(a, b) == pytest.approx(want, rel=1e-12)
+
+
+def test_pairwise_chamfer_table(gpu):
+    """utils/pc_dist.py:45-99: table[i,j] = two-directional Chamfer, 200 on the diagonal."""
+    from scipy.spatial import KDTree
+
+    from corsair_amd.utils import pc_dist
+
+    rng = np.random.default_rng(2)
+    pcs = [rng.uniform(-1, 1, (n, 3)).astype(np.float32) for n in (300, 257, 512, 64, 100)]
+    table = pc_dist.compute_dist(pcs)
+    assert table.shape == (5, 5) and np.allclose(np.diag(table), 200.0) and np.allclose(table, table.T)
+    for i in range(5):
+        for j in range(i + 1, 5):
+            a, b = pcs[i].astype(np.float64), pcs[j].astype(np.float64)
+            want = KDTree(a).query(b)[0].mean() + KDTree(b).query(a)[0].mean()
+            assert table[i, j] == pytest.approx(want, rel=1e-10)
+    assert pc_dist.chamfer(pcs[0], pcs[1]) == pytest.approx(table[0, 1], rel=1e-12)
+
+
+def test_shapenet_style_registration_eval(gpu):
+    """evaluation-shapenet.py:242-343 end to end on two synthetic models x 2 poses; every result
+    equals the per-pair oracle sym_pose on the same features."""
+    from corsair_amd import harness, registration as R, shapenet_eval as S, synth
+    from oracle import post
+
+    sd, emb = synth.make_state_dicts(31)
+    pipe = harness.Pipeline(sd, emb, device=gpu)
+    cfg = S.Config(n_poses_per_model=2, ransac_max_iter=2000, max_translation=0.5)
+    clouds = [synth.make_cloud(50, 6000), _ring_cloud(4, n=6000, seed=3, jitter=0.002)]
+    res = S.evaluate(pipe, clouds, cfg, pairs_per_batch=4)
+    assert len(res) == 4
+    assert [r["symmetry_label"] for r in res] == [S.get_symmetry_label(S.load_pc(clouds[0]), 0.1)] * 2 + \
+        [S.get_symmetry_label(S.load_pc(clouds[1]), 0.1)] * 2
+    assert res[2]["symmetry_label"] in (4, 8, 12)
+    for r in res:
+        assert r["chamfer_dist_sym"] <= r["chamfer_dist_ransac"]
+        assert np.isfinite(r["rre_sym"]) and 0 <= r["rre_sym"] <= np.pi
+    tab = S.threshold_table(res)
+    assert set(tab) == {"ransac", "sym"} and 0.0 <= tab["sym"]["rre<=45"] <= 1.0
+    # oracle re-run of the first pair on the GPU features
+    rng = np.random.default_rng(cfg.random_seed)
+    pc = S.load_pc(clouds[0])
+    pose = S.generate_random_pose(cfg, rng)
+    xyz = torch.from_numpy(np.concatenate([pc.astype(np.float32),
+                                           (pc @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32)])).to(gpu)
+    es = pipe.embed_batch_raw(xyz, [0, len(pc), 2 * len(pc)], cfg.voxel_size)
+    o = es.offsets
+    F, X = es.F.cpu().numpy(), es.origin.cpu().numpy()
+    a0 = R.draw_anchors(o[1], 100, 0)
+    a1 = R.draw_anchors(o[2] - o[1], 100, 1)
+    Tb, cdb, Tr, cdr, ok = post.sym_pose(F[:o[1]], X[:o[1]], F[o[1]:], X[o[1]:], res[0]["symmetry_label"], 5,
+                                         cfg.max_corr, 0, a0, a1, cfg.ransac_max_iter, cfg.ransac_confidence)
+    assert np.array_equal(res[0]["T_est_ransac"], Tr) and np.array_equal(res[0]["T_est_sym"], Tb)
+    assert res[0]["sym_success"] == ok
