@@ -8,6 +8,8 @@
 // to the smaller index.  These kernels are VALU(f64)-bound with every operand staged through LDS
 // (targets) or held in registers (queries); HBM traffic is the algorithmic minimum (each row read
 // once per query tile).
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -253,6 +255,188 @@ __global__ void k_topk_finish(const unsigned long long* carry_d, const int* carr
 }
 
 // ------------------------------------------------------------------------------------------
+// Large-scale descriptor top-k (BASELINE config C5: 10^6 x 10^6 x 256-d, top-10) on the f64 matrix
+// pipe.  d^2 = |q|^2 + |x|^2 - 2 q.x with the dot products on v_mfma_f64_16x16x4_f64 (absolute error
+// ~1e-15 for unit descriptors) is used ONLY to shortlist: every lane keeps the TKM_KK best rows of
+// the catalog rows it sees for its query; the shortlist (k + margin per lane) is then re-scored with
+// the canonical chain sum_c (q_c - x_c)^2 and ranked by (distance, index), so the returned ids and
+// distances are those of the exact kernel unless more than `margin` catalog rows tie with the k-th
+// neighbour to within ~2e-15 -- the same caveat cdist itself has.
+// ------------------------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int TKM_QT = 64;     // queries per block (16 per wave)
+constexpr int TKM_XT = 64;     // catalog rows per tile
+constexpr int TKM_DC = 64;     // feature chunk in LDS
+constexpr int TKM_PITCH = TKM_DC + 2;  // doubles; 2*(pitch) = 4 mod 64 banks: conflict-free b64 reads
+constexpr int TKM_KK = 12;     // shortlist per lane (k <= TKM_KK - 2)
+
+__global__ void k_row_norms(const float* __restrict__ X, int64_t n, int d, double* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < d; ++c) {
+    const double v = (double)X[i * d + c];
+    s = fma(v, v, s);
+  }
+  out[i] = s;
+}
+
+// grid: x = query tile, y = catalog split.  cand_*: [nq][nsplit*4][TKM_KK]
+__global__ __launch_bounds__(256) void k_topk_mfma(const float* __restrict__ Q, int64_t nq,
+                                                   const float* __restrict__ X, int64_t nx, int d,
+                                                   const double* __restrict__ qn,
+                                                   const double* __restrict__ xn, int nsplit,
+                                                   double* __restrict__ cand_d,
+                                                   int* __restrict__ cand_i) {
+  __shared__ double q_lds[TKM_QT * TKM_PITCH];
+  __shared__ double x_lds[TKM_XT * TKM_PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 15;   // query within the wave's 16, and catalog row within an MFMA tile (A side)
+  const int kq = lane >> 4;    // k slot of the operands, and row group of the results
+  const int64_t q0 = (int64_t)blockIdx.x * TKM_QT;
+  const int64_t per = ((nx + nsplit - 1) / nsplit + TKM_XT - 1) / TKM_XT * TKM_XT;
+  const int64_t xb = (int64_t)blockIdx.y * per;
+  const int64_t xe = min(nx, xb + per);
+  const int64_t my_q = q0 + wave * 16 + col;
+  const double my_qn = my_q < nq ? qn[my_q] : 0.0;
+
+  double bd[TKM_KK];
+  int bi[TKM_KK];
+#pragma unroll
+  for (int j = 0; j < TKM_KK; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+
+  for (int64_t x0 = xb; x0 < xe; x0 += TKM_XT) {
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < d; c0 += TKM_DC) {
+      const int dc = min(TKM_DC, d - c0);
+      __syncthreads();
+      for (int i = tid; i < TKM_QT * TKM_DC; i += 256) {
+        const int r = i / TKM_DC, c = i - r * TKM_DC;
+        double v = 0.0;
+        if (q0 + r < nq && c < dc) v = (double)Q[(q0 + r) * d + c0 + c];
+        q_lds[r * TKM_PITCH + c] = v;
+      }
+      for (int i = tid; i < TKM_XT * TKM_DC; i += 256) {
+        const int r = i / TKM_DC, c = i - r * TKM_DC;
+        double v = 0.0;
+        if (x0 + r < xe && c < dc) v = (double)X[(x0 + r) * d + c0 + c];
+        x_lds[r * TKM_PITCH + c] = v;
+      }
+      __syncthreads();
+      const double* qp = q_lds + (wave * 16 + col) * TKM_PITCH + kq;
+      const double* xp = x_lds + col * TKM_PITCH + kq;
+#pragma unroll 4
+      for (int k4 = 0; k4 < TKM_DC; k4 += 4) {
+        const double b = qp[k4];                       // B[k][query]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double a = xp[t * 16 * TKM_PITCH + k4];  // A[catalog row][k]
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // results: acc[t][r] = dot(catalog row x0 + 16 t + kq + 4 r, query my_q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = x0 + 16 * t + kq + 4 * r;
+        double dist = INFINITY;
+        if (row < xe) dist = fma(-2.0, acc[t][r], my_qn + xn[row]);
+        if (dist < bd[TKM_KK - 1]) {
+          double cd = dist;
+          int ci = (int)row;
+          bool carry = false;
+#pragma unroll
+          for (int s2 = 0; s2 < TKM_KK; ++s2) {
+            if (carry || cd < bd[s2]) {
+              carry = true;
+              const double td = bd[s2];
+              const int ti = bi[s2];
+              bd[s2] = cd;
+              bi[s2] = ci;
+              cd = td;
+              ci = ti;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (my_q < nq) {
+    const int64_t base = (my_q * (nsplit * 4) + blockIdx.y * 4 + kq) * TKM_KK;
+#pragma unroll
+    for (int j = 0; j < TKM_KK; ++j) {
+      cand_d[base + j] = bd[j];
+      cand_i[base + j] = bi[j];
+    }
+  }
+}
+
+// Re-score the shortlist of one query with the canonical chain and keep the k best (dist, idx).
+constexpr int TKM_MERGE_CAP = 1024;
+__global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ Q,
+                                                      const float* __restrict__ X, int d,
+                                                      const int* __restrict__ cand_i, int ncand,
+                                                      int k, unsigned long long* carry_d,
+                                                      int* carry_i) {
+  __shared__ unsigned long long sd[TKM_MERGE_CAP];
+  __shared__ int si[TKM_MERGE_CAP];
+  const int tid = threadIdx.x;
+  const int64_t qi = blockIdx.x;
+  const unsigned long long INF_BITS = 0x7ff0000000000000ULL;
+  for (int i = tid; i < TKM_MERGE_CAP; i += 256) {
+    unsigned long long dv = INF_BITS;
+    int iv = 0x7fffffff;
+    if (i < ncand) {
+      const int row = cand_i[qi * ncand + i];
+      if (row != 0x7fffffff) {
+        double acc = 0.0;
+        for (int c = 0; c < d; ++c) {
+          const double diff = (double)Q[qi * d + c] - (double)X[(int64_t)row * d + c];
+          acc = fma(diff, diff, acc);
+        }
+        dv = (unsigned long long)__double_as_longlong(acc);
+        iv = row;
+      }
+    }
+    sd[i] = dv;
+    si[i] = iv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= TKM_MERGE_CAP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < TKM_MERGE_CAP / 2; t += 256) {
+        const int lo = (t / stride) * stride * 2 + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long dl = sd[lo], dh = sd[hi];
+        const int il = si[lo], ih = si[hi];
+        const bool swap = up ? key_less(dh, ih, dl, il) : key_less(dl, il, dh, ih);
+        if (swap) {
+          sd[lo] = dh;
+          si[lo] = ih;
+          sd[hi] = dl;
+          si[hi] = il;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += 256) {
+    carry_d[qi * k + i] = sd[i];
+    carry_i[qi * k + i] = si[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // one-directional Chamfer
 // ------------------------------------------------------------------------------------------
 struct ChamferWork {
@@ -410,7 +594,34 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   CS_REQUIRE(nx < (1LL << 31), CS_ERR_UNSUPPORTED, "cs_l2_topk: catalog too large");
   if (nq == 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof("topk", s);
+  ProfScope prof("topk", s, 2.0 * (double)nq * (double)nx * (double)d);
+  // large problems with a short list: shortlist on the f64 matrix pipe, exact re-score
+  const char* force = getenv("CS_TOPK_MFMA");
+  const bool big = (double)nq * (double)nx >= 16777216.0;
+  if (k <= TKM_KK - 2 && ((force && force[0] == '1') || (!force && big))) {
+    int nsplit = (int)(2048 / ceil_div(nq, TKM_QT));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 64) nsplit = 64;
+    while (nsplit > 1 && (nx / nsplit < 4 * TKM_XT || nsplit * 4 * TKM_KK > TKM_MERGE_CAP)) --nsplit;
+    const int ncand = nsplit * 4 * TKM_KK;
+    PoolBuf<double> qn(nq), xn(nx), cand_d((size_t)nq * ncand);
+    PoolBuf<int> cand_i((size_t)nq * ncand);
+    PoolBuf<unsigned long long> cd((size_t)nq * k);
+    PoolBuf<int> ci((size_t)nq * k);
+    CS_REQUIRE(qn.p && xn.p && cand_d.p && cand_i.p && cd.p && ci.p, CS_ERR_HIP,
+               "cs_l2_topk: scratch allocation failed");
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn.p);
+    hipLaunchKernelGGL(k_topk_mfma, dim3((unsigned)ceil_div(nq, TKM_QT), (unsigned)nsplit), dim3(256), 0,
+                       s, d_q, nq, d_x, nx, d, qn.p, xn.p, nsplit, cand_d.p, cand_i.p);
+    hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand,
+                       k, cd.p, ci.p);
+    hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
+                       ci.p, nq * k, d_idx, d_dist);
+    CS_LAUNCH_CHECK();
+    CS_HIP_CHECK(hipStreamSynchronize(s));
+    return CS_OK;
+  }
   // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
   int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);
   if (slab < DM_CT) slab = DM_CT;

@@ -206,3 +206,41 @@ def test_sym_pose_matches_oracle(gpu, oracle_native):
         assert float(res.cd_ransac[p]) == pytest.approx(cdr, rel=1e-12)
         assert float(res.cd_best[p]) == pytest.approx(cdb, rel=1e-12)
         assert float(res.cd_best[p]) <= float(res.cd_ransac[p])  # invariant of the caches
+
+
+@pytest.mark.parametrize("nq,nx,d,k", [(37, 5000, 256, 10), (5, 70, 256, 3), (300, 9000, 512, 1),
+                                       (130, 20000, 100, 10)])
+def test_l2_topk_mfma_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, nq, nx, d, k):
+    """The f64-MFMA shortlist + exact re-score path (config C5 sizes) returns exactly the ids and
+    distances of the canonical chain, duplicates (exact ties) included."""
+    from corsair_amd import backend as B, synth
+
+    monkeypatch.setenv("CS_TOPK_MFMA", "1")
+    q = synth.make_descriptors(nq, d, seed=11)
+    x = synth.make_descriptors(nx, d, seed=12)
+    x[7] = x[3]
+    x[nx - 1] = x[3]
+    idx, dist = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(x).to(gpu), k, True)
+    d2 = oracle_native.dist2_matrix(q, x)
+    want = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
+
+
+def test_l2_topk_large_matches_exact_slab_path(gpu, monkeypatch):
+    """Stress-shaped run (65 536 x 262 144 x 256, top-10): MFMA path == exact slab path on a sample of
+    queries, and the size-independent properties hold (sorted distances, unique ids, idempotent)."""
+    from corsair_amd import backend as B, synth
+
+    nq, nx = 65536, 262144
+    q = torch.from_numpy(synth.make_descriptors(nq, 256, seed=1234)).to(gpu)
+    x = torch.from_numpy(synth.make_descriptors(nx, 256, seed=4321)).to(gpu)
+    idx, dist = B.l2_topk(q, x, 10, True)
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    assert bool((idx >= 0).all()) and bool((idx < nx).all())
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    sample = torch.arange(0, nq, 1021, device=gpu)
+    monkeypatch.setenv("CS_TOPK_MFMA", "0")
+    idx_ref, dist_ref = B.l2_topk(q[sample].contiguous(), x, 10, True)
+    assert torch.equal(idx[sample], idx_ref) and torch.equal(dist[sample], dist_ref)
