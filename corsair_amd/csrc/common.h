@@ -108,6 +108,11 @@ struct cs_coordmap {
   uint64_t* d_keys = nullptr;    // [capacity]
   int32_t* d_vals = nullptr;     // [capacity]
   uint64_t capacity = 0;         // power of two
+  // per-sample row segments (rows grouped by batch index), filled lazily for the LDS kernel-map path
+  int32_t* d_seg = nullptr;      // [n_batch + 1]
+  int n_batch = 0;
+  int max_seg = 0;
+  int seg_state = 0;             // 0 unknown, 1 available, -1 rows are not grouped by sample
 };
 
 struct cs_kernelmap {

@@ -10,6 +10,9 @@
 // batch (145k voxels -> 4.7 MB of table) stay L2/Infinity-Cache resident between the insert
 // and the 27 probes per output row.
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
+
+#include <vector>
 
 #include "common.h"
 
@@ -112,10 +115,11 @@ __global__ void k_emit_strided(const int32_t* __restrict__ coords, int64_t n, in
 __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_out, int kvol,
                             int step, int sign, const uint64_t* __restrict__ keys,
                             const int32_t* __restrict__ vals, uint64_t mask, int32_t* nbr,
-                            unsigned long long* pair_count) {
+                            unsigned long long* pair_count,
+                            const int* __restrict__ sample_mask) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int found = 0;
-  if (t < n_out * kvol) {
+  if (t < n_out * kvol && (!sample_mask || sample_mask[out_coords[4 * (t / kvol)]])) {
     int64_t o = t / kvol;
     int k = (int)(t - o * kvol);
     int dx = 0, dy = 0, dz = 0;
@@ -136,6 +140,165 @@ __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_ou
   // wave-level count then one atomic per wave
   unsigned long long m = __ballot(found);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel maps built in LDS.  Coordinates of a batch are grouped by sample (collate order), and a
+// kernel-map probe never leaves its sample, so one workgroup loads the in-map coordinates of ONE
+// sample into an LDS hash table (30-bit keys relative to the sample's bounding box, 16-bit local row)
+// and answers all 27 probes of its slice of output rows from LDS -- no random global access at all.
+// Samples with more than LDS_MAX_ROWS voxels or bounding boxes wider than 1023 cells are flagged and
+// handled by the global-table kernel (k_build_nbr, restricted to the flagged samples); batches that
+// are not grouped by sample use the global kernel for everything.
+// ------------------------------------------------------------------------------------------------
+constexpr int LDS_SLOTS = 24576;      // 4-B keys + 2-B local rows = 144 KB of the CU's 160 KB LDS
+constexpr int LDS_MAX_ROWS = 15360;   // load factor <= 0.625
+constexpr uint32_t LDS_EMPTY = 0xffffffffu;
+
+// seg[b] = first row whose batch index is >= b (rows must be grouped by ascending batch index).
+__global__ void k_segments(const int32_t* __restrict__ coords, int64_t n, int n_batch,
+                           int32_t* __restrict__ seg, int* __restrict__ flags) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = coords[4 * i];
+  const int prev = i > 0 ? coords[4 * (i - 1)] : -1;
+  if (b < prev || b >= n_batch || b < 0) {
+    atomicOr(&flags[0], 1);  // not grouped by sample
+    return;
+  }
+  for (int bb = prev + 1; bb <= b; ++bb) seg[bb] = (int32_t)i;
+  if (i == n - 1)
+    for (int bb = b + 1; bb <= n_batch; ++bb) seg[bb] = (int32_t)n;
+}
+__global__ void k_segment_max(const int32_t* __restrict__ seg, int n_batch, int* __restrict__ flags) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_batch) atomicMax(&flags[1], seg[b + 1] - seg[b]);
+}
+
+// grid: x = slice of the sample's output rows, y = sample.  block = 1024 threads.
+__global__ __launch_bounds__(1024) void k_build_nbr_lds(
+    const int32_t* __restrict__ in_coords, const int32_t* __restrict__ in_seg,
+    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int step,
+    int sign, int32_t* __restrict__ nbr, unsigned long long* __restrict__ pair_count,
+    int* __restrict__ fallback) {
+  __shared__ uint32_t keys[LDS_SLOTS];
+  __shared__ uint16_t vals[LDS_SLOTS];
+  __shared__ int bmin[3], bmax[3];
+  const int b = blockIdx.y;
+  const int i0 = in_seg[b], i1 = in_seg[b + 1];
+  const int o0 = out_seg[b], o1 = out_seg[b + 1];
+  const int tid = threadIdx.x;
+  if (o1 <= o0) return;
+  const int per = (o1 - o0 + gridDim.x - 1) / gridDim.x;
+  const int s0 = o0 + blockIdx.x * per, s1 = min(o1, s0 + per);
+  if (s0 >= s1) return;
+  if (tid < 3) {
+    bmin[tid] = 0x7fffffff;
+    bmax[tid] = -0x7fffffff;
+  }
+  for (int i = tid; i < LDS_SLOTS; i += 1024) keys[i] = LDS_EMPTY;
+  __syncthreads();
+  for (int i = i0 + tid; i < i1; i += 1024) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int v = in_coords[4 * i + 1 + a];
+      atomicMin(&bmin[a], v);
+      atomicMax(&bmax[a], v);
+    }
+  }
+  __syncthreads();
+  const int mx = bmin[0], my = bmin[1], mz = bmin[2];
+  const int ex = i1 > i0 ? (bmax[0] - mx) / unit : 0, ey = i1 > i0 ? (bmax[1] - my) / unit : 0,
+            ez = i1 > i0 ? (bmax[2] - mz) / unit : 0;
+  if (ex > 1023 || ey > 1023 || ez > 1023 || i1 - i0 > LDS_MAX_ROWS) {
+    if (tid == 0) fallback[b] = 1;
+    return;
+  }
+  for (int i = i0 + tid; i < i1; i += 1024) {
+    const uint32_t key = (uint32_t)((in_coords[4 * i + 1] - mx) / unit) |
+                         ((uint32_t)((in_coords[4 * i + 2] - my) / unit) << 10) |
+                         ((uint32_t)((in_coords[4 * i + 3] - mz) / unit) << 20);
+    uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
+    while (true) {
+      const uint32_t old = atomicCAS(&keys[slot], LDS_EMPTY, key);
+      if (old == LDS_EMPTY || old == key) {
+        vals[slot] = (uint16_t)(i - i0);  // coordinates are unique inside a map
+        break;
+      }
+      slot = slot + 1 == LDS_SLOTS ? 0 : slot + 1;
+    }
+  }
+  __syncthreads();
+  int found_total = 0;
+  const int total = (s1 - s0) * 27;
+  for (int t = tid; t < total; t += 1024) {
+    const int o = s0 + t / 27;
+    const int k = t - (t / 27) * 27;
+    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+    const int x = out_coords[4 * o + 1] + sign * dx * step - mx;
+    const int y = out_coords[4 * o + 2] + sign * dy * step - my;
+    const int z = out_coords[4 * o + 3] + sign * dz * step - mz;
+    int32_t v = -1;
+    if (x >= 0 && y >= 0 && z >= 0 && x % unit == 0 && y % unit == 0 && z % unit == 0) {
+      const int cx = x / unit, cy = y / unit, cz = z / unit;
+      if (cx <= ex && cy <= ey && cz <= ez) {
+        const uint32_t key = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
+        uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
+        while (true) {
+          const uint32_t kk = keys[slot];
+          if (kk == key) {
+            v = i0 + (int32_t)vals[slot];
+            break;
+          }
+          if (kk == LDS_EMPTY) break;
+          slot = slot + 1 == LDS_SLOTS ? 0 : slot + 1;
+        }
+      }
+    }
+    nbr[(int64_t)o * 27 + k] = v;
+    found_total += v >= 0;
+  }
+  // block-level pair count: wave reduce, one atomic per wave
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) found_total += __shfl_xor(found_total, off);
+  if ((tid & 63) == 0 && found_total) atomicAdd(pair_count, (unsigned long long)found_total);
+}
+
+// Per-sample segment table of a coordinate map (computed once, cached on the map).
+static int ensure_segments(cs_coordmap* m, hipStream_t s) {
+  if (m->seg_state != 0) return CS_OK;
+  m->seg_state = -1;  // unavailable unless everything below succeeds
+  if (m->n == 0) return CS_OK;
+  int32_t last_b = -1;
+  CS_HIP_CHECK(hipMemcpyAsync(&last_b, m->d_coords + 4 * (m->n - 1), sizeof(int32_t),
+                              hipMemcpyDeviceToHost, s));
+  CS_HIP_CHECK(hipStreamSynchronize(s));
+  if (last_b < 0 || last_b >= 65536) return CS_OK;
+  const int nb = last_b + 1;
+  int32_t* seg = (int32_t*)pool_alloc((size_t)(nb + 1) * sizeof(int32_t));
+  PoolBuf<int> flags(2);
+  if (!seg || !flags.p) {
+    pool_free(seg);
+    return CS_OK;
+  }
+  int h_flags[2] = {0, 0};
+  CS_HIP_CHECK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  CS_HIP_CHECK(hipMemsetAsync(seg, 0, (size_t)(nb + 1) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_segments, dim3((unsigned)ceil_div(m->n, 256)), dim3(256), 0, s, m->d_coords,
+                     m->n, nb, seg, flags.p);
+  hipLaunchKernelGGL(k_segment_max, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, s, seg, nb,
+                     flags.p);
+  CS_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  CS_HIP_CHECK(hipStreamSynchronize(s));
+  if (h_flags[0]) {
+    pool_free(seg);
+    return CS_OK;  // not grouped by sample: global path
+  }
+  m->d_seg = seg;
+  m->n_batch = nb;
+  m->max_seg = h_flags[1];
+  m->seg_state = 1;
+  return CS_OK;
 }
 
 // 27-bit neighbour-presence mask of every output row + identity row ids (sorted by mask afterwards)
@@ -357,6 +520,7 @@ void cs_coordmap_free(cs_coordmap* m) {
   pool_free(m->d_coords);
   pool_free(m->d_keys);
   pool_free(m->d_vals);
+  pool_free(m->d_seg);
   delete m;
 }
 
@@ -398,14 +562,48 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
   }
   unsigned long long h_cnt = 0;
   hipError_t e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s);
-  if (e == hipSuccess && total > 0) {
+  // LDS path: per-sample hash tables (see k_build_nbr_lds); otherwise the global table
+  bool used_lds = false, need_global = false;
+  PoolBuf<int> fb;
+  if (e == hipSuccess && total > 0 && km->kvol == 27 && getenv("CS_KMAP_GLOBAL") == nullptr) {
+    cs_coordmap* in_m = const_cast<cs_coordmap*>(in);
+    cs_coordmap* out_m = const_cast<cs_coordmap*>(out);
+    if (ensure_segments(in_m, s) == CS_OK && ensure_segments(out_m, s) == CS_OK &&
+        in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch &&
+        true) {
+      const int nb = in_m->n_batch;
+      fb.alloc(nb);
+      std::vector<int> h_fb(nb, 0);
+      if (fb.p) {
+        int slices = 512 / (nb > 0 ? nb : 1);
+        if (slices < 1) slices = 1;
+        if (slices > 8) slices = 8;
+        e = hipMemsetAsync(fb.p, 0, sizeof(int) * nb, s);
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL(k_build_nbr_lds, dim3((unsigned)slices, (unsigned)nb), dim3(1024), 0, s,
+                             in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
+                             in->tensor_stride, step, sign, km->d_nbr, cnt.p, fb.p);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(h_fb.data(), fb.p, sizeof(int) * nb, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+          used_lds = true;
+          for (int b = 0; b < nb; ++b) need_global = need_global || h_fb[b] != 0;
+        }
+      }
+    }
+  }
+  if (e == hipSuccess && total > 0 && (!used_lds || need_global)) {
     hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        out->d_coords, km->n_out, km->kvol, step, sign, in->d_keys, in->d_vals,
-                       in->capacity - 1, km->d_nbr, cnt.p);
+                       in->capacity - 1, km->d_nbr, cnt.p, used_lds ? fb.p : (const int*)nullptr);
     e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     cs_kernelmap_free(km);
     set_error("cs_kernelmap_build: %s", hipGetErrorString(e));

@@ -80,3 +80,36 @@ def test_resunet_forward_bit_exact(gpu, oracle_native):
     assert np.array_equal(feat.cpu().numpy(), want_feat)
     assert np.array_equal(out.cpu().numpy(), want_out)
     assert np.array_equal(g.cpu().numpy(), want_g)
+
+
+def test_kernel_maps_lds_path_with_fallback_samples(gpu):
+    """LDS-built kernel maps: a batch mixing an ordinary sample, one too large for the LDS table
+    (> 15 360 voxels), one with a bounding box wider than 1023 cells and an empty batch index; the
+    flagged samples go through the global-table kernel.  Also: rows not grouped by sample."""
+    from oracle import resunet as oref
+    from oracle import sparse as osp
+
+    rng = np.random.default_rng(9)
+
+    def cloud(n, span):
+        g = rng.integers(-span, span, (n, 3))
+        _, first = np.unique(g, axis=0, return_index=True)
+        return g[np.sort(first)]
+
+    parts = [cloud(3000, 12), cloud(40000, 20), np.array([[0, 0, 0], [3000, 1, 2], [3001, 1, 2], [1, 0, 0]]),
+             np.zeros((0, 3), np.int64), cloud(500, 6)]
+    assert len(parts[1]) > 15360
+    coords = np.concatenate([np.concatenate([np.full((len(p), 1), b), p], 1) for b, p in enumerate(parts)]).astype(np.int32)
+    m = _maps(gpu, coords)
+    omaps, okm = oref.build_maps(coords)
+    for name, nbr in okm.items():
+        km = getattr(m, name)
+        assert np.array_equal(km.table().cpu().numpy(), nbr), name
+        assert km.num_pairs == int((nbr >= 0).sum()), name
+    # interleaved batch indices (not grouped): whole map falls back to the global table
+    perm = rng.permutation(len(coords))
+    shuffled = coords[perm]
+    m2 = _maps(gpu, shuffled)
+    _, okm2 = oref.build_maps(shuffled)
+    for name in ("s1", "s1_s2", "s2_s1_T"):
+        assert np.array_equal(getattr(m2, name).table().cpu().numpy(), okm2[name]), name
