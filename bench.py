@@ -53,13 +53,20 @@ def main():
     from corsair_amd import _lib, harness, sharding, synth
 
     _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; CORSAIR_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
+    # N > 1 code path on a single-GPU box (RCCL needs distinct devices)
+    backend = os.environ.get("CORSAIR_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = harness.Config()
     sd, emb = synth.make_state_dicts(cfg.random_seed)
@@ -139,7 +146,7 @@ def main():
     _lib.prof_enable(False)
     log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

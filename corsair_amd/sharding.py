@@ -28,20 +28,29 @@ def global_order(n, world):
     return np.argsort(np.concatenate([np.arange(r, n, world) for r in range(world)]), kind="stable")
 
 
+def _stage_device(dist, t):
+    """RCCL moves device tensors; gloo (CPU rehearsal / tests) is given host tensors."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return t.device
+
+
 def _all_gather_padded(dist, t, rows, world):
     """all_gather of a 2-D tensor whose row count differs per rank (padded to `rows`)."""
-    pad = torch.zeros((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-    pad[: t.shape[0]] = t
+    stage = _stage_device(dist, t)
+    pad = torch.zeros((rows,) + tuple(t.shape[1:]), device=stage, dtype=t.dtype)
+    pad[: t.shape[0]] = t.to(stage)
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return out
+    return [o.to(t.device) for o in out]
 
 
 def all_gather_embedded(dist, eset, world):
     """All-gather an EmbeddedSet (descriptors + voxel features + origins + offsets).  Returns the
     list of per-rank sets."""
     dev = eset.F.device
-    sizes_local = torch.tensor([eset.F.shape[0], len(eset)], device=dev, dtype=torch.int64)
+    sizes_local = torch.tensor([eset.F.shape[0], len(eset)], device=_stage_device(dist, eset.F),
+                               dtype=torch.int64)
     sizes = [torch.zeros_like(sizes_local) for _ in range(world)]
     dist.all_gather(sizes, sizes_local)
     sizes = torch.stack(sizes).cpu().numpy()
