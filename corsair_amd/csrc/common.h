@@ -63,10 +63,6 @@ struct PoolBuf {
   }
 };
 
-// Pinned host staging buffer (reused, grows).  Not thread safe across host threads by design:
-// the reference drives this path from one Python thread (SURVEY 8b "Threading").
-void* pinned_scratch(size_t bytes, int slot);
-
 // Profiling (cs_prof_*).
 struct ProfScope {
   int id;

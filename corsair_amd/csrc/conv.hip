@@ -292,6 +292,7 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
                 int cin, const float* d_w, int cout, const float* d_scale, const float* d_shift,
                 const float* d_residual, int ld_res, int relu, float* d_out, int ld_out,
                 void* stream) {
+  if (n_out == 0 && n_in == 0) return CS_OK;  // empty batch (empty torch tensors have NULL storage)
   CS_REQUIRE(d_in && d_w && d_out, CS_ERR_INVALID, "cs_conv_fwd: NULL tensor");
   CS_REQUIRE(cin >= 1 && cout >= 1 && ld_in >= cin && ld_out >= cout, CS_ERR_INVALID,
              "cs_conv_fwd: bad channel / leading dimension (cin %d ld_in %d cout %d ld_out %d)",

@@ -649,8 +649,8 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
 static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float* d_tgt,
                           const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
                           int n_prob, const float* d_T, int reduce_max, double* d_out, void* stream) {
-  CS_REQUIRE(d_src && d_tgt && h_soff && h_toff && h_src_seg && h_tgt_seg && d_T && d_out,
-             CS_ERR_INVALID, "cs_chamfer_1dir: NULL argument");
+  CS_REQUIRE(h_soff && h_toff && h_src_seg && h_tgt_seg && d_T && d_out, CS_ERR_INVALID,
+             "cs_chamfer_1dir: NULL argument");
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   std::vector<ChamferWork> work;
@@ -676,6 +676,7 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
     }
   }
   slot_begin[n_prob] = (int32_t)work.size();
+  CS_REQUIRE(work.empty() || (d_src && d_tgt), CS_ERR_INVALID, "cs_chamfer_1dir: NULL point array");
   PoolBuf<ChamferWork> dwork;
   PoolBuf<int32_t> dslot;
   PoolBuf<int64_t> dcount;

@@ -570,7 +570,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                     float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
                     float* d_T, int32_t* d_inliers, double* d_rmse, int32_t* d_iters,
                     void* stream) {
-  CS_REQUIRE(d_src && d_tgt && h_off && d_T, CS_ERR_INVALID, "cs_ransac_batch: NULL argument");
+  CS_REQUIRE(h_off && d_T, CS_ERR_INVALID, "cs_ransac_batch: NULL argument");
   CS_REQUIRE(ransac_n >= 3 && ransac_n <= 64, CS_ERR_INVALID,
              "cs_ransac_batch: ransac_n %d not in [3, 64]", ransac_n);
   CS_REQUIRE(max_corr > 0.f && max_iter >= 1, CS_ERR_INVALID,
@@ -581,6 +581,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = h_off[n_prob] - h_off[0];
   CS_REQUIRE(h_off[0] == 0 && total >= 0, CS_ERR_INVALID, "cs_ransac_batch: bad offsets");
+  CS_REQUIRE(total == 0 || (d_src && d_tgt), CS_ERR_INVALID, "cs_ransac_batch: NULL correspondences");
 
   std::vector<RansacProb> hp(n_prob);
   int m_max = 0;

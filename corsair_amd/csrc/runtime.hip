@@ -1,4 +1,4 @@
-// Library runtime: error string, scratch pool, pinned staging, per-kernel-family profiling.
+// Library runtime: error string, scratch pool, per-kernel-family profiling.
 #include <stdarg.h>
 
 #include <map>
@@ -70,26 +70,6 @@ void pool_free(void* p) {
   if (it == g_live.end()) return;
   g_free[it->second].push_back(p);
   g_live.erase(it);
-}
-
-static void* g_pinned[8] = {nullptr};
-static size_t g_pinned_sz[8] = {0};
-
-void* pinned_scratch(size_t bytes, int slot) {
-  if (slot < 0 || slot >= 8) return nullptr;
-  if (g_pinned_sz[slot] < bytes) {
-    if (g_pinned[slot]) (void)hipHostFree(g_pinned[slot]);
-    size_t c = 4096;
-    while (c < bytes) c <<= 1;
-    if (hipHostMalloc(&g_pinned[slot], c, hipHostMallocDefault) != hipSuccess) {
-      g_pinned[slot] = nullptr;
-      g_pinned_sz[slot] = 0;
-      set_error("hipHostMalloc(%zu) failed", c);
-      return nullptr;
-    }
-    g_pinned_sz[slot] = c;
-  }
-  return g_pinned[slot];
 }
 
 // ---- profiling -----------------------------------------------------------------------------

@@ -1,0 +1,97 @@
+"""Edge cases through the C ABI on the GPU: empty and ragged inputs, error conventions (status < 0 +
+cs_last_error -> RuntimeError like ME), duplicates, out-of-range coordinates, tiny problems."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_conventions(gpu):
+    from corsair_amd import _lib, backend as B
+
+    dup = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3], [0, 0, 0, 0]], dtype=torch.int32, device=gpu)
+    with pytest.raises(_lib.CorsairHipError, match="duplicate"):
+        B.CoordMap.create(dup)
+    far = torch.tensor([[0, 40000, 0, 0]], dtype=torch.int32, device=gpu)
+    with pytest.raises(_lib.CorsairHipError, match="range"):
+        B.CoordMap.create(far)
+    neg = torch.tensor([[-1, 0, 0, 0]], dtype=torch.int32, device=gpu)
+    with pytest.raises(_lib.CorsairHipError):
+        B.CoordMap.create(neg)
+    ok = B.CoordMap.create(torch.tensor([[0, 0, 0, 0], [0, 5, 5, 5]], dtype=torch.int32, device=gpu))
+    km = B.KernelMap.build(ok, ok)
+    x = torch.ones((2, 8), device=gpu)
+    with pytest.raises(ValueError):
+        B.conv_fwd(km, x, torch.ones((27, 4, 8), device=gpu))          # channel mismatch
+    with pytest.raises(_lib.CorsairHipError):
+        B.conv_fwd(km, torch.ones((3, 8), device=gpu), torch.ones((27, 8, 8), device=gpu))  # row mismatch
+    with pytest.raises(_lib.CorsairHipError):
+        B.l2_topk(torch.ones((2, 4), device=gpu), torch.ones((3, 4), device=gpu), 5)         # k > nx
+    with pytest.raises(_lib.CorsairHipError):
+        B.knn_feat(torch.ones((2, 16), device=gpu), [0, 2], torch.ones((4, 16), device=gpu), [0, 4], 9)
+    with pytest.raises(TypeError):
+        B.conv_fwd(km, x.double(), torch.ones((27, 8, 8), device=gpu))
+    # a failed call leaves the library usable
+    assert B.conv_fwd(km, x, torch.ones((27, 8, 8), device=gpu)).shape == (2, 8)
+
+
+def test_empty_and_tiny_inputs(gpu, oracle_native):
+    from corsair_amd import backend as B
+
+    empty = B.CoordMap.create(torch.zeros((0, 4), dtype=torch.int32, device=gpu))
+    assert empty.n == 0 and empty.stride(2).n == 0
+    km = B.KernelMap.build(empty, empty)
+    assert km.num_pairs == 0 and km.n_out == 0
+    out = B.conv_fwd(km, torch.zeros((0, 32), device=gpu), torch.ones((27, 32, 32), device=gpu))
+    assert out.shape == (0, 32)
+    # single voxel: only the centre offset is present
+    one = B.CoordMap.create(torch.tensor([[0, 3, -4, 5]], dtype=torch.int32, device=gpu))
+    k1 = B.KernelMap.build(one, one)
+    t = k1.table().cpu().numpy()
+    assert k1.num_pairs == 1 and t[0, 13] == 0 and (np.delete(t[0], 13) == -1).all()
+    w = torch.randn((27, 32, 64), device=gpu)
+    x = torch.randn((1, 32), device=gpu)
+    got = B.conv_fwd(k1, x, w).cpu().numpy()
+    want = oracle_native.conv_fwd(t, x.cpu().numpy(), w.cpu().numpy())
+    assert np.array_equal(got, want)
+    # negative coordinates: floor division in the strided map
+    neg = torch.tensor([[0, -1, -1, -1], [0, -2, 0, 1], [0, 1, 1, 1]], dtype=torch.int32, device=gpu)
+    m = B.CoordMap.create(neg).stride(2)
+    assert m.coords.cpu().numpy().tolist() == [[0, -2, -2, -2], [0, -2, 0, 0], [0, 0, 0, 0]]
+    # segmented max with an absent sample, RANSAC / kNN / Chamfer with empty segments
+    feats = torch.tensor([[1.0, -2.0], [3.0, -5.0], [-1.0, -1.0]], device=gpu)
+    coords = torch.tensor([[0, 0, 0, 0], [0, 1, 0, 0], [2, 0, 0, 0]], dtype=torch.int32, device=gpu)
+    mx = B.segmented_max(feats, coords, 3).cpu().numpy()
+    assert mx[0].tolist() == [3.0, -2.0] and np.isneginf(mx[1]).all() and mx[2].tolist() == [-1.0, -1.0]
+    T, inl, rmse, iters = B.ransac_batch(torch.zeros((0, 3), device=gpu), torch.zeros((0, 3), device=gpu),
+                                         [0, 0, 0], 0.2, 10, 100, 0.999, 0)
+    assert torch.equal(T.cpu(), torch.eye(4).repeat(2, 1, 1)) and inl.cpu().tolist() == [0, 0]
+    idx = B.knn_feat(torch.ones((3, 16), device=gpu), [0, 3], torch.ones((2, 16), device=gpu), [0, 2], 5)
+    assert idx.cpu().numpy()[:, :2].tolist() == [[0, 1]] * 3 and (idx.cpu().numpy()[:, 2:] == -1).all()
+    cd = B.chamfer_1dir(torch.zeros((0, 3), device=gpu), [0, 0], torch.ones((2, 3), device=gpu), [0, 2],
+                        [0], [0], torch.eye(4, device=gpu)[None])
+    assert torch.isnan(cd).all()
+
+
+def test_ragged_batch_forward_row_order(gpu):
+    """Batch of clouds with very different sizes: per-sample row segments stay in input order."""
+    from corsair_amd import engine, synth
+    from tests.helpers import make_batch
+
+    coords, feats, _, offsets = make_batch([60, 61, 62], n_points=800)
+    coords2, feats2, _, _ = make_batch([63], n_points=9000)
+    coords2[:, 0] = 3
+    allc = np.concatenate([coords, coords2])
+    sd, emb = synth.make_state_dicts(31)
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    out, feat, maps = eng.forward(torch.from_numpy(allc).to(gpu),
+                                  torch.ones((len(allc), 1), device=gpu))
+    assert np.array_equal(maps.c1.coords.cpu().numpy(), allc)
+    g = eng.embed(feat, maps, 4)
+    # each sample's result is independent of its batch mates: rerun the big cloud alone
+    solo = coords2.copy()
+    solo[:, 0] = 0
+    out1, feat1, maps1 = eng.forward(torch.from_numpy(solo).to(gpu), torch.ones((len(solo), 1), device=gpu))
+    g1 = eng.embed(feat1, maps1, 1)
+    assert torch.equal(out[len(coords):], out1) and torch.equal(g[3], g1[0])
