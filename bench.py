@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 F32_PEAK_TFLOPS = 157.3   # MI355X f32: matrix (v_mfma_f32_32x32x2_f32) == vector peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6
+F16_PEAK_TFLOPS = 2516.6  # dense f16/bf16 MFMA: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (16x the f32 matrix rate)
 BATCH = 32
 N_CATALOG = 652
 N_QUERY_POOL = 993
@@ -166,20 +167,26 @@ def main():
 
     if rank == 0:
         fam = {}
-        for name in ("conv", "ransac_eval", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap"):
+        for name in ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut",
+                     "kmap"):
             ms, n, units = _lib.prof_get(name)
             fam[name] = {"ms": ms, "launches": n, "flop": units}
-        dom = max(("conv", "ransac_eval", "knn", "chamfer"), key=lambda k: fam[k]["ms"])
+        dom = max(("conv", "ransac_eval", "ransac_pre", "knn", "chamfer"), key=lambda k: fam[k]["ms"])
         d = fam[dom]
-        peak = F64_PEAK_TFLOPS if dom in ("knn", "chamfer") else F32_PEAK_TFLOPS
+        peak = {"knn": F64_PEAK_TFLOPS, "chamfer": F64_PEAK_TFLOPS, "ransac_pre": F16_PEAK_TFLOPS}.get(
+            dom, F32_PEAK_TFLOPS)
         achieved = (d["flop"] / max(d["launches"], 1)) / (max(d["ms"], 1e-9) / max(d["launches"], 1) * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_count",
+                                                  "ransac_pre": "k_ransac_prefilter",
                                                   "knn": "k_knn_feat", "chamfer": "k_chamfer"}[dom],
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
                     "launches": d["launches"],
                     "flop_per_launch": d["flop"] / max(d["launches"], 1),
-                    "note": "f32 matrix peak == f32 vector peak on gfx950 (157.3 TF); see DESIGN.md"}
+                    "note": ("k_ransac_prefilter: 94 FLOP per (hypothesis, pair) = the 47 f16 multiply-adds of "
+                             "the hi/lo residual expansion, against the dense f16 MFMA peak; conv / "
+                             "k_ransac_count are priced against the f32 matrix peak (157.3 TF), kNN / Chamfer "
+                             "against the f64 matrix peak; see DESIGN.md")}
         # HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run of this same
         # command (FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -243,11 +243,15 @@ constexpr int RC_CHUNK = RC_CHUNK_SZ;     // correspondences per LDS stage (mult
 constexpr int RC_STG = RC_CHUNK / 256;    // staged rows per thread
 constexpr int RC_TILES = RC_CHUNK / 32;   // 32-correspondence MFMA tiles per stage
 
+// LIST: the hypotheses are the survivors of the prefilter, hlist[p][0 .. n_surv[p]) (any order).
+template <bool LIST>
 __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
                                                       const float* __restrict__ pk, int64_t total,
                                                       const float* __restrict__ hyp, int it0,
                                                       int bcount, int bmax, int splits, float thr2,
-                                                      int32_t* __restrict__ res_cnt) {
+                                                      int32_t* __restrict__ res_cnt,
+                                                      const int32_t* __restrict__ hlist,
+                                                      const int32_t* __restrict__ n_surv) {
   // [buf][c][j]: c = 0..2 source xyz, c = 3..5 NEGATED target xyz (the MFMA accumulator input)
   __shared__ __attribute__((aligned(16))) float lds[2][6][RC_CHUNK];
   const int p = blockIdx.y;
@@ -255,18 +259,24 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
   const int split = blockIdx.x - tile * splits;
   const RansacProb pr = probs[p];
   if (pr.done) return;
-  if (it0 + tile * 128 >= pr.est_k || tile * 128 >= bcount) return;  // whole block beyond the bound
+  const int nlist = LIST ? n_surv[p] : 0;
+  if (LIST) {
+    if (tile * 128 >= nlist) return;
+  } else {
+    if (it0 + tile * 128 >= pr.est_k || tile * 128 >= bcount) return;  // whole block beyond the bound
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction
   const int half = lane >> 5;
   const int col = lane & 31;
-  const int h0 = tile * 128 + wave * 32;                  // first hypothesis of this wave
-  const bool wave_live = h0 < bcount && it0 + h0 < pr.est_k;
+  const int h0 = tile * 128 + wave * 32;                  // first hypothesis (slot) of this wave
+  const bool wave_live = LIST ? h0 < nlist : (h0 < bcount && it0 + h0 < pr.est_k);
+  const int hsel = LIST ? hlist[(int64_t)p * bmax + min(h0 + col, nlist - 1)] : h0 + col;
   // B operands of this lane: hypothesis column h0 + col, k-slot = half
   float b1[3], b2[3];
   {
-    const int hh = min(h0 + col, bmax - 1);
+    const int hh = min(hsel, bmax - 1);
     const float* hp = hyp + ((int64_t)p * 12) * bmax + hh;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -367,12 +377,309 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
   if (!wave_live) return;
   cnt += __shfl_xor(cnt, 32);  // the two half-waves own disjoint correspondence rows
   const int h = h0 + col;
-  if (half == 0 && h < bcount && it0 + h < pr.est_k) {
+  const bool mine = LIST ? h < nlist : (h < bcount && it0 + h < pr.est_k);
+  if (half == 0 && mine) {
     if (splits == 1)
-      res_cnt[(int64_t)p * bmax + h] = cnt;
+      res_cnt[(int64_t)p * bmax + hsel] = cnt;
     else
-      atomicAdd(&res_cnt[(int64_t)p * bmax + h], cnt);
+      atomicAdd(&res_cnt[(int64_t)p * bmax + hsel], cnt);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exactness-preserving f16 prefilter.
+// Once a problem has a best inlier count, a hypothesis matters only if its own count can reach it
+// (otherwise it changes neither the best, nor the early-exit bound, nor the tie set).  The squared
+// residual is bilinear in hypothesis and pair quantities,
+//   |R s + t - q|^2 = |t|^2 + [1, 2 R^T t, -2 R, -2 t] . [|s|^2 + |q|^2, s, q (x) s, q]     (16 terms)
+// Every term is split into f16 hi + lo; hi*hi + hi*lo + lo*hi (47 products, K = 48) is three
+// v_mfma_f32_32x32x16_f16 per 32 x 32 tile (16x the f32 matrix rate) whose accumulator INPUT holds
+// |t|^2 - (thr^2 + eps_h): the sign of the result says whether the pair is within the INFLATED
+// threshold.  eps_h bounds |d~^2 - d^2| (k_ransac_hyp16), so the sign count is an UPPER bound of the
+// exact inlier count.  Hypotheses whose bound is below the carried best get count 0, the few
+// survivors go through the exact f32 kernel: results are unchanged bit for bit.
+// ------------------------------------------------------------------------------------------------
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int PF_K = 48;        // halfs per operand row (96 B)
+constexpr int PF_PITCH = 56;    // halfs per LDS row (112 B = 7 slots of 16 B: conflict-free ds_read_b128)
+constexpr int PF_ROWS = 128;    // pairs per LDS stage (4 MFMA row tiles)
+constexpr int PF_NG = 2;        // 32-hypothesis groups per wave (LDS fragments are reused NG times)
+constexpr int PF_HYP = 4 * 32 * PF_NG;  // hypotheses per workgroup
+constexpr float PF_SMAX = 128.0f;       // point norm above which a problem bypasses the prefilter
+                                        // (f16 range: |s|^2 + |q|^2 and q (x) s must stay below 65504)
+
+__device__ __forceinline__ void split16(double v, _Float16* hi, _Float16* lo) {
+  const _Float16 h = (_Float16)v;
+  *hi = h;
+  *lo = (_Float16)(v - (double)h);
+}
+
+__global__ void k_ransac_prob_of(const RansacProb* __restrict__ probs, int32_t* __restrict__ prob_of) {
+  const RansacProb pr = probs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pr.m; i += gridDim.x * blockDim.x)
+    prob_of[pr.off + i] = blockIdx.y;
+}
+
+// pair side: row = [bh(0..15) | bl(0..15) | bh(1..15), 0];  smax[p] = largest point norm of problem p
+__global__ void k_ransac_pack16(const float* __restrict__ src, const float* __restrict__ tgt,
+                                const int32_t* __restrict__ prob_of, int64_t n,
+                                _Float16* __restrict__ B16, unsigned* __restrict__ smax_bits) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+  const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
+  const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
+  double b[16];
+  b[0] = ss + qq;
+  b[1] = sx; b[2] = sy; b[3] = sz;
+  b[4] = qx * sx; b[5] = qx * sy; b[6] = qx * sz;
+  b[7] = qy * sx; b[8] = qy * sy; b[9] = qy * sz;
+  b[10] = qz * sx; b[11] = qz * sy; b[12] = qz * sz;
+  b[13] = qx; b[14] = qy; b[15] = qz;
+  _Float16 row[PF_K];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    _Float16 hi, lo;
+    split16(b[k], &hi, &lo);
+    row[k] = hi;
+    row[16 + k] = lo;
+    if (k) row[31 + k] = hi;
+  }
+  row[47] = (_Float16)0.0f;
+  uint4* dst = reinterpret_cast<uint4*>(B16 + i * PF_K);
+  const uint4* r4 = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dst[k] = r4[k];
+  // 1.0000002: the f32 norm below may round down
+  const float mag = 1.0000002f * (float)sqrt(fmax(ss, qq));
+  if (!(mag <= PF_SMAX)) {  // out of f16 range (or NaN): a finite (zero) row; the problem's
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);  // hypotheses all become "unusable" via smax
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k] = z;
+  }
+  atomicMax(&smax_bits[prob_of[i]], __float_as_uint(mag));  // non-negative floats order like uints
+}
+
+// hypothesis side: row = [ah(0..15) | ah(0..15) | al(1..15), 0] and the accumulator input
+//   c_h = |t|^2 - (thr^2 + eps_h).
+// eps_h >= |d~^2 - d^2| where d^2 is what the exact kernel computes and d~^2 the f16 pipeline:
+//   * 47 products, exact in f32; their accumulation rounds (or truncates) at most 48 times relative
+//     to sum_k |a_k b_k| <= sqrt(3) (|s| + |q| + |t|)^2 =: sqrt(3) W            <= 48 * 2^-23 * sqrt(3) W
+//   * dropped lo*lo products and the residuals of the hi+lo splits      <= 3 * 2^-22 * sqrt(3) W + 2^-25 (2 W + 59)
+//   * the exact kernel's own f32 rounding of d^2                        <= 2^-20 W
+//   => < 3e-5 W + 2e-6; charged 1.2e-4 W + 1e-5 (4x margin; validated by CS_RANSAC_CHECK runs)
+//   * |R s|^2 = |s|^2 only up to the orthonormality defect E = R^T R - I:    <= 3 max|E| smax^2
+// with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
+// a zero row: every pair counts, it always survives to the exact kernel.
+__global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float* __restrict__ hyp,
+                               const unsigned* __restrict__ smax_bits, int it0, int bcount, int bmax,
+                               float thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
+  const int p = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= bcount) return;
+  const RansacProb pr = probs[p];
+  if (pr.done || it0 + h >= pr.est_k) return;
+  const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
+  double R[3][3], t[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[a][b] = (double)hp[(int64_t)(4 * a + b) * bmax];
+    t[a] = (double)hp[(int64_t)(4 * a + 3) * bmax];
+  }
+  const double smax = (double)__uint_as_float(smax_bits[p]);
+  const double tt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+  const double tn = sqrt(tt);
+  double a[16];
+  a[0] = 1.0;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) a[1 + b] = 2.0 * (R[0][b] * t[0] + R[1][b] * t[1] + R[2][b] * t[2]);
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) a[4 + 3 * x + b] = -2.0 * R[x][b];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) a[13 + x] = -2.0 * t[x];
+  double dev = 0.0;
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int y = 0; y < 3; ++y) {
+      const double e = R[0][x] * R[0][y] + R[1][x] * R[1][y] + R[2][x] * R[2][y] - (x == y ? 1.0 : 0.0);
+      dev = fmax(dev, fabs(e));
+    }
+  bool usable = smax <= (double)PF_SMAX && tn <= 4.0 * (double)PF_SMAX && dev < 1.0e-3;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) usable = usable && fabs(a[k]) < 6.0e4;  // false for NaN
+  _Float16 row[PF_K];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
+    if (usable) split16(a[k], &hi, &lo);
+    row[k] = hi;
+    row[16 + k] = hi;
+    if (k) row[31 + k] = lo;
+  }
+  row[47] = (_Float16)0.0f;
+  uint4* dst = reinterpret_cast<uint4*>(A16 + ((int64_t)p * bmax + h) * PF_K);
+  const uint4* r4 = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dst[k] = r4[k];
+  const double w = 2.0 * smax + tn;
+  const double eps = 1.2e-4 * w * w + 1.0e-5 + 3.0 * dev * smax * smax;
+  // rounded towards -inf so that the f32 value never tightens the test
+  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - ((double)thr2 + eps)) : -INFINITY;
+}
+
+// Upper bounds of the inlier counts.  grid: x = hypothesis tile (PF_HYP) * splits, y = problem.
+// MFMA operand maps (v_mfma_f32_32x32x16_f16): lane l supplies A[row l&31][k = 8(l>>5) .. +8) and
+// B[k = 8(l>>5) .. +8)][col l&31]; D as for the f32 shape.  rows = pairs (LDS), cols = hypotheses
+// (registers, PF_NG groups per wave).
+__global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __restrict__ probs,
+                                                          const _Float16* __restrict__ B16,
+                                                          const _Float16* __restrict__ A16,
+                                                          const float* __restrict__ c_h, int it0,
+                                                          int bcount, int bmax, int splits,
+                                                          int32_t* __restrict__ cnt_up) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2][PF_ROWS * PF_PITCH];
+  const int p = blockIdx.y;
+  const int tile = blockIdx.x / splits;
+  const int split = blockIdx.x - tile * splits;
+  const RansacProb pr = probs[p];
+  if (pr.done) return;
+  if (it0 + tile * PF_HYP >= pr.est_k || tile * PF_HYP >= bcount) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int col = lane & 31;
+  const int h0 = tile * PF_HYP + wave * 32 * PF_NG;
+  const bool wave_live = h0 < bcount && it0 + h0 < pr.est_k;
+  f16x8 bop[PF_NG][3];
+  f32x16 cin[PF_NG];
+#pragma unroll
+  for (int g = 0; g < PF_NG; ++g) {
+    // hypotheses past the chunk / bound read a valid row; their result is not stored
+    int hh = h0 + 32 * g + col;
+    if (hh >= bcount || it0 + hh >= pr.est_k) hh = h0;
+    const _Float16* row = A16 + ((int64_t)p * bmax + hh) * PF_K + 8 * half;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) bop[g][m] = *reinterpret_cast<const f16x8*>(row + 16 * m);
+    const float c = c_h[(int64_t)p * bmax + hh];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cin[g][r] = c;
+    asm volatile("" : "+v"(cin[g]));  // keep the 16 copies resident instead of re-splatting per tile
+  }
+  const int per = ((pr.m + splits - 1) / splits + PF_ROWS - 1) / PF_ROWS * PF_ROWS;
+  const int beg = split * per;
+  const int end = min(pr.m, beg + per);
+  unsigned bits[PF_NG];
+  int cnt[PF_NG];
+#pragma unroll
+  for (int g = 0; g < PF_NG; ++g) {
+    bits[g] = 0u;
+    cnt[g] = 0;
+  }
+
+  // staging: 128 rows x 96 B per stage, 48 B per thread (row = tid / 2, half row = tid % 2)
+  uint4 stg[3];
+  const int s_row = tid >> 1, s_part = tid & 1;
+  auto stage_load = [&](int base) {
+    const int i = base + s_row;
+    const int64_t g = pr.off + (i < end ? i : 0);
+    const uint4* src = reinterpret_cast<const uint4*>(B16 + g * PF_K + 24 * s_part);
+    stg[0] = src[0];
+    stg[1] = src[1];
+    stg[2] = src[2];
+  };
+  auto stage_store = [&](int b, int base) {
+    if (base + s_row >= end) {  // padding row: d~^2 = 60000 + c_h, positive for every usable hypothesis
+      stg[0] = make_uint4(s_part == 0 ? 0x7b53u : 0u, 0u, 0u, 0u);  // f16 60000 in element 0 (a_0 = 1)
+      stg[1] = make_uint4(0u, 0u, 0u, 0u);
+      stg[2] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(&lds[b][s_row * PF_PITCH + 24 * s_part]);
+    dst[0] = stg[0];
+    dst[1] = stg[1];
+    dst[2] = stg[2];
+  };
+  if (beg < end) {
+    stage_load(beg);
+    stage_store(0, beg);
+  }
+  int buf = 0;
+  for (int base = beg; base < end; base += PF_ROWS) {
+    __syncthreads();
+    const bool more = base + PF_ROWS < end;
+    if (more) stage_load(base + PF_ROWS);
+    if (wave_live) {
+#pragma unroll
+      for (int t = 0; t < PF_ROWS / 32; ++t) {
+        const _Float16* arow = &lds[buf][(t * 32 + col) * PF_PITCH + 8 * half];
+        f16x8 a[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const f16x8*>(arow + 16 * m);
+#pragma unroll
+        for (int g = 0; g < PF_NG; ++g) {
+          __builtin_amdgcn_s_setprio(1);
+          f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bop[g][0], cin[g], 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bop[g][1], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bop[g][2], d, 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          // shift the 16 sign bits into the per-lane history word: one VALU op per pair
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            bits[g] = __builtin_amdgcn_alignbit(bits[g], __float_as_uint(d[r]), 31);
+          if (t & 1) cnt[g] += __popc(bits[g]);  // 32 fresh bits every second tile
+        }
+      }
+    }
+    if (more) stage_store(buf ^ 1, base + PF_ROWS);
+    buf ^= 1;
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int g = 0; g < PF_NG; ++g) {
+    const int c = cnt[g] + __shfl_xor(cnt[g], 32);
+    const int h = h0 + 32 * g + col;
+    if (half == 0 && h < bcount && it0 + h < pr.est_k) {
+      if (splits == 1)
+        cnt_up[(int64_t)p * bmax + h] = c;
+      else
+        atomicAdd(&cnt_up[(int64_t)p * bmax + h], c);
+    }
+  }
+}
+
+// Survivors: hypotheses whose upper bound reaches the carried best count.  The others get count 0.
+__global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const int32_t* __restrict__ cnt_up,
+                                   int it0, int bcount, int bmax, int32_t* __restrict__ res_cnt,
+                                   int32_t* __restrict__ hlist, int32_t* __restrict__ n_surv) {
+  const int p = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= bcount) return;
+  const RansacProb pr = probs[p];
+  if (pr.done || it0 + h >= pr.est_k) return;
+  res_cnt[(int64_t)p * bmax + h] = 0;
+  if (cnt_up[(int64_t)p * bmax + h] >= pr.best_cnt) {
+    const int slot = atomicAdd(&n_surv[p], 1);
+    hlist[(int64_t)p * bmax + slot] = h;
+  }
+}
+
+// Debug check (CS_RANSAC_CHECK=1): the bound must dominate the exact count of every hypothesis.
+__global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const int32_t* __restrict__ exact,
+                                     const int32_t* __restrict__ cnt_up, int it0, int bcount, int bmax,
+                                     unsigned long long* __restrict__ stats) {
+  const int p = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= bcount) return;
+  const RansacProb pr = probs[p];
+  if (pr.done || it0 + h >= pr.est_k) return;
+  const int e = exact[(int64_t)p * bmax + h], u = cnt_up[(int64_t)p * bmax + h];
+  if (e > u) atomicAdd(&stats[0], 1ULL);
+  atomicAdd(&stats[1], 1ULL);
+  atomicAdd(&stats[2], (unsigned long long)(u - e > 0 ? u - e : 0));
 }
 
 // est_k implied by a best inlier count c (Open3D: log(1 - confidence) / log(1 - ratio^n))
@@ -564,7 +871,18 @@ __global__ void k_ransac_finish(const RansacProb* __restrict__ probs, int n_prob
 
 using namespace cs;
 
+// prefilter diagnostics: {bound violations, hypotheses checked, sum of (bound - exact)} from
+// CS_RANSAC_CHECK runs, {survivors, hypotheses evaluated} always
+static unsigned long long g_pf_stats[5] = {0, 0, 0, 0, 0};
+
 extern "C" {
+
+void cs_ransac_prefilter_stats(uint64_t out[5], int reset) {
+  for (int i = 0; i < 5; ++i) {
+    if (out) out[i] = g_pf_stats[i];
+    if (reset) g_pf_stats[i] = 0;
+  }
+}
 
 int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off, int n_prob,
                     float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
@@ -603,6 +921,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // 32-query batch, so the partially filled last wave costs ~10 % instead of ~33 % at 4096.
   const int bmax = 16384;
   const int64_t tot1 = total ? total : 1;
+  // f16 prefilter (see k_ransac_prefilter): on from the third chunk, when every live problem normally
+  // carries a best count; CS_RANSAC_PREFILTER=0 disables it, CS_RANSAC_CHECK=1 verifies the bound
+  // against the exact count of EVERY hypothesis (slow; tests).
+  const char* env_pf = getenv("CS_RANSAC_PREFILTER");
+  const char* env_ck = getenv("CS_RANSAC_CHECK");
+  const bool use_pf = !(env_pf && env_pf[0] == '0') && total > 0;
+  const bool check = use_pf && env_ck && env_ck[0] == '1';
+  const int pf_from = 512;
   PoolBuf<RansacProb> probs(n_prob);
   PoolBuf<float> pk((size_t)tot1 * 6);
   PoolBuf<float> hyp((size_t)n_prob * 12 * bmax);
@@ -611,11 +937,32 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   PoolBuf<int> n_active(1);
   CS_REQUIRE(probs.p && pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p && n_active.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
+  const bool pf_alloc = use_pf && max_iter > pf_from;
+  PoolBuf<_Float16> B16(pf_alloc ? (size_t)tot1 * PF_K : 8), A16(pf_alloc ? (size_t)n_prob * bmax * PF_K : 8);
+  PoolBuf<float> c_h(pf_alloc ? (size_t)n_prob * bmax : 1);
+  PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
+  PoolBuf<int32_t> n_surv(n_prob), prob_of(pf_alloc ? (size_t)tot1 : 1);
+  PoolBuf<unsigned> smax_bits(n_prob);
+  PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
+  PoolBuf<unsigned long long> chk_stats(4);
+  CS_REQUIRE(B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && n_surv.p && prob_of.p && smax_bits.p &&
+                 exact_dbg.p && chk_stats.p,
+             CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
+  std::vector<int32_t> h_surv(n_prob);
   CS_HIP_CHECK(hipMemcpyAsync(probs.p, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
     hipLaunchKernelGGL(k_ransac_pack, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        d_src, d_tgt, total, pk.p);
+    CS_LAUNCH_CHECK();
+  }
+  if (pf_alloc) {
+    CS_HIP_CHECK(hipMemsetAsync(smax_bits.p, 0, sizeof(unsigned) * n_prob, s));
+    CS_HIP_CHECK(hipMemsetAsync(chk_stats.p, 0, sizeof(unsigned long long) * 4, s));
+    hipLaunchKernelGGL(k_ransac_prob_of, dim3((unsigned)ceil_div(m_max > 0 ? m_max : 1, 256), (unsigned)n_prob),
+                       dim3(256), 0, s, probs.p, prob_of.p);
+    hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
+                       d_src, d_tgt, prob_of.p, total, B16.p, smax_bits.p);
     CS_LAUNCH_CHECK();
   }
   // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
@@ -624,11 +971,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   (void)frexpf(thr2, &ex);
   const float scale = ldexpf(1.0f, 31 - ex);
   const double log_1mc = log(1.0 - confidence);  // -inf when confidence == 1: never exits early
+  unsigned long long st_surv = 0, st_eval = 0;
 
   int it0 = 0;
   while (it0 < max_iter) {
     int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
     if (b > max_iter - it0) b = max_iter - it0;
+    const bool pf = pf_alloc && it0 >= pf_from;
     const int tiles = (b + 127) / 128;
     // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
     // chunk is small (integer partial sums combine exactly)
@@ -641,24 +990,68 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
                          dim3(256), 0, s, probs.p, d_src, d_tgt, it0, b, bmax, ransac_n, seed, hyp.p);
     }
-    if (splits > 1)  // partial counts of the splits are combined with integer atomics
-      CS_HIP_CHECK(hipMemset2DAsync(res_cnt.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
-                                    n_prob, s));
     CS_HIP_CHECK(hipMemsetAsync(n_active.p, 0, sizeof(int), s));
     // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
     // (transform 18 + squared distance 8 + compare/accumulate)
-    double eval_flop = 0.0;
+    double eval_pairs = 0.0;
     for (int p = 0; p < n_prob; ++p) {
       if (hp[p].done) continue;
       int nh = hp[p].est_k - it0;
       if (nh > b) nh = b;
-      if (nh > 0) eval_flop += 30.0 * (double)nh * (double)hp[p].m;
+      if (nh > 0) {
+        eval_pairs += (double)nh * (double)hp[p].m;
+        st_eval += (unsigned long long)nh;
+      }
     }
-    {
-      ProfScope prof("ransac_eval", s, eval_flop);
-      hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
+    if (!pf) {
+      if (splits > 1)  // partial counts of the splits are combined with integer atomics
+        CS_HIP_CHECK(hipMemset2DAsync(res_cnt.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
+                                      n_prob, s));
+      ProfScope prof("ransac_eval", s, 30.0 * eval_pairs);
+      hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
                          dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
-                         res_cnt.p);
+                         res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    } else {
+      const int ptiles = (b + PF_HYP - 1) / PF_HYP;
+      int psplits = (int)(2048 / ((int64_t)n_prob * ptiles));
+      if (psplits < 1) psplits = 1;
+      if (psplits > 16) psplits = 16;
+      while (psplits > 1 && m_max / psplits < 2 * PF_ROWS) --psplits;
+      hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
+                         0, s, probs.p, hyp.p, smax_bits.p, it0, b, bmax, thr2, A16.p, c_h.p);
+      CS_HIP_CHECK(hipMemsetAsync(n_surv.p, 0, sizeof(int32_t) * n_prob, s));
+      if (psplits > 1)
+        CS_HIP_CHECK(hipMemset2DAsync(cnt_up.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
+                                      n_prob, s));
+      {
+        // 94 FLOP per (hypothesis, pair): the 47 multiply-adds of the hi/lo expansion
+        ProfScope prof("ransac_pre", s, 94.0 * eval_pairs);
+        hipLaunchKernelGGL(k_ransac_prefilter, dim3((unsigned)(ptiles * psplits), (unsigned)n_prob),
+                           dim3(256), 0, s, probs.p, B16.p, A16.p, c_h.p, it0, b, bmax, psplits,
+                           cnt_up.p);
+      }
+      hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
+                         dim3(256), 0, s, probs.p, cnt_up.p, it0, b, bmax, res_cnt.p, hlist.p, n_surv.p);
+      // exact counts of the survivors; few hypotheses, so the pair range is split finely
+      int lsplits = 16;
+      while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
+      {
+        ProfScope prof("ransac_eval", s);
+        hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(tiles * lsplits), (unsigned)n_prob),
+                           dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
+                           res_cnt.p, hlist.p, n_surv.p);
+      }
+      if (check) {
+        CS_HIP_CHECK(hipMemset2DAsync(exact_dbg.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
+                                      n_prob, s));
+        hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
+                           dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                           exact_dbg.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_ransac_check_bound, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
+                           dim3(256), 0, s, probs.p, exact_dbg.p, cnt_up.p, it0, b, bmax, chk_stats.p);
+      }
+      CS_HIP_CHECK(hipMemcpyAsync(h_surv.data(), n_surv.p, sizeof(int32_t) * n_prob,
+                                  hipMemcpyDeviceToHost, s));
     }
     hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(64), 0, s, probs.p, n_prob,
                        res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, n_active.p);
@@ -671,11 +1064,28 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     CS_HIP_CHECK(hipMemcpyAsync(&h_active, n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
     // the per-problem state (est_k, done) comes back with the activity counter: it sizes the next
     // chunk's work accounting and costs one small copy behind a synchronisation we need anyway
+    std::vector<RansacProb> prev;
+    if (pf) prev = hp;
     CS_HIP_CHECK(hipMemcpyAsync(hp.data(), probs.p, sizeof(RansacProb) * n_prob,
                                 hipMemcpyDeviceToHost, s));
     CS_HIP_CHECK(hipStreamSynchronize(s));
+    if (pf)
+      for (int p = 0; p < n_prob; ++p)
+        if (!prev[p].done) st_surv += (unsigned long long)h_surv[p];
     it0 += b;
     if (h_active == 0) break;
+  }
+  g_pf_stats[3] += st_surv;
+  g_pf_stats[4] += st_eval;
+  if (check) {
+    unsigned long long h_stats[4] = {0, 0, 0, 0};
+    CS_HIP_CHECK(hipMemcpyAsync(h_stats, chk_stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    CS_HIP_CHECK(hipStreamSynchronize(s));
+    g_pf_stats[0] += h_stats[0];
+    g_pf_stats[1] += h_stats[1];
+    g_pf_stats[2] += h_stats[2];
+    CS_REQUIRE(h_stats[0] == 0, CS_ERR_INTERNAL,
+               "cs_ransac_batch: prefilter bound violated for %llu hypotheses", h_stats[0]);
   }
   hipLaunchKernelGGL(k_ransac_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
                      probs.p, n_prob, (double)scale, d_T, d_inliers, d_rmse, d_iters);

@@ -73,8 +73,8 @@ void pool_free(void* p) {
 }
 
 // ---- profiling -----------------------------------------------------------------------------
-static const char* kProfNames[] = {"conv",    "ransac_eval", "ransac_hyp", "knn",
-                                   "chamfer", "topk",        "symcut",     "kmap"};
+static const char* kProfNames[] = {"conv",    "ransac_eval", "ransac_hyp", "knn",       "chamfer",
+                                   "topk",    "symcut",      "kmap",       "ransac_pre"};
 static constexpr int kNumProf = sizeof(kProfNames) / sizeof(kProfNames[0]);
 static int g_prof_on = 0;
 struct ProfPending {

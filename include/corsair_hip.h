@@ -35,6 +35,7 @@ extern "C" {
 #define CS_ERR_RANGE (-3)
 #define CS_ERR_DUPLICATE (-4)
 #define CS_ERR_UNSUPPORTED (-5)
+#define CS_ERR_INTERNAL (-6) /* a self-check of the library failed (e.g. CS_RANSAC_CHECK) */
 
 typedef struct cs_coordmap cs_coordmap;   /* coordinates of one tensor stride + hash index */
 typedef struct cs_kernelmap cs_kernelmap; /* output-stationary neighbour table of one conv  */
@@ -188,6 +189,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                     float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
                     float* d_T, int32_t* d_inliers, double* d_rmse, int32_t* d_iters,
                     void* stream);
+/* Diagnostics of the inlier-count prefilter inside cs_ransac_batch (an f16 matrix-core pass that
+ * computes an UPPER bound of every hypothesis' inlier count; only hypotheses whose bound reaches
+ * the current best are evaluated exactly, so results do not change).  out = {bound violations,
+ * hypotheses checked, sum of (bound - exact)} accumulated by runs with the environment variable
+ * CS_RANSAC_CHECK=1 (which recomputes every hypothesis exactly and fails with CS_ERR_INTERNAL on a
+ * violation), then {survivors, hypotheses generated} of every run.  CS_RANSAC_PREFILTER=0 turns the
+ * prefilter off. */
+void cs_ransac_prefilter_stats(uint64_t out[5], int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Symmetry part cut.  Replaces symmetric_cut4 (utils/symmetry.py:182-259) for a batch of
@@ -213,7 +222,8 @@ int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, cons
 /* ------------------------------------------------------------------------------------------
  * Profiling hooks for bench.py: when enabled the library brackets the launches of each named
  * kernel family with hipEvents on the launch stream and accumulates the elapsed time.
- * names: "conv", "ransac_eval", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap".
+ * names: "conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut",
+ * "kmap".
  * ---------------------------------------------------------------------------------------- */
 void cs_prof_enable(int on);
 void cs_prof_reset(void);

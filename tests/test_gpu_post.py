@@ -146,6 +146,58 @@ def test_ransac_seed_changes_samples_but_not_quality(gpu):
         assert np.abs(T[:3, :3] - Tgt[:3, :3]).max() < 0.1
 
 
+def _prefilter_stats(reset=False):
+    import ctypes
+
+    from corsair_amd import _lib
+
+    out = (ctypes.c_uint64 * 5)()
+    _lib.load().cs_ransac_prefilter_stats(out, int(reset))
+    return [int(v) for v in out]
+
+
+@pytest.mark.parametrize("scale,max_corr", [(1.0, 0.2), (1.0, 0.03), (6.0, 0.5), (11.0, 1.5), (40.0, 4.0), (100.0, 10.0)])
+def test_ransac_prefilter_bound_and_identity(gpu, oracle_native, monkeypatch, scale, max_corr):
+    """The f16 matrix-core prefilter must (a) never under-estimate an inlier count (CS_RANSAC_CHECK
+    recomputes every hypothesis exactly) and (b) leave the result bit-identical to the exact-only
+    path and to the oracle, at every coordinate scale (100: beyond the f16 range -> bypass; 40: bound valid but loose)."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(int(scale * 10) + 3)
+    specs = [(3500, 0.04, 0), (2200, 0.08, 1), (1300, 0.03, 2), (4100, 0.02, 3), (700, 0.12, 4), (2900, 0.0, 5)]
+    probs = []
+    for m, f, i in specs:
+        src, tgt, _ = _corr_problem(rng, m, f, noise=0.02, pose_id=i)
+        probs.append(((src * scale).astype(np.float32), (tgt * scale).astype(np.float32)))
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+    max_iter = 40000
+
+    def run():
+        return [t.cpu().numpy() for t in B.ransac_batch(S, D, off, max_corr, 10, max_iter, 0.999, 7)]
+
+    monkeypatch.setenv("CS_RANSAC_PREFILTER", "0")
+    exact = run()
+    monkeypatch.setenv("CS_RANSAC_PREFILTER", "1")
+    monkeypatch.setenv("CS_RANSAC_CHECK", "1")
+    _prefilter_stats(reset=True)
+    checked = run()                      # raises CorsairHipError on a bound violation
+    viol, n_checked, slack, surv, gen = _prefilter_stats()
+    assert viol == 0 and n_checked > 0
+    monkeypatch.delenv("CS_RANSAC_CHECK")
+    plain = run()
+    for a, b, c in zip(exact, checked, plain):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    if scale <= 6.0:
+        # the bound has to be useful, not just valid: most hypotheses are pruned
+        assert surv < 0.25 * n_checked, (surv, n_checked)
+    for p in (1, 4):
+        wT, winl, wrmse, wit = oracle_native.ransac(probs[p][0], probs[p][1], max_corr, 10, max_iter, 0.999, 7)
+        assert exact[1][p] == winl and exact[3][p] == wit
+        assert np.array_equal(exact[0][p], wT)
+
+
 def _engine_features(gpu, cloud_ids, pose_ids):
     from corsair_amd import engine, synth
     from tests.helpers import make_batch

@@ -28,5 +28,8 @@ for rep in range(2):
     sym = np.ones(C, np.int32); sym[::326]=4
     t=time.time(); res = pipe.register(qs, cads, sym[top], use_symmetry=False); torch.cuda.synchronize(); log('register nosym', time.time()-t, res.iters.cpu().numpy()[:8])
     t=time.time(); res = pipe.register(qs, cads, sym[top]); torch.cuda.synchronize(); log('register sym', time.time()-t, res.n_problems, res.ok[:8], res.iters.cpu().numpy()[:12])
-for name in ("conv","ransac_eval","ransac_hyp","knn","chamfer","topk","symcut","kmap"):
+for name in ("conv","ransac_eval","ransac_pre","ransac_hyp","knn","chamfer","topk","symcut","kmap"):
     log(name, _lib.prof_get(name))
+import ctypes
+st = (ctypes.c_uint64 * 5)(); _lib.load().cs_ransac_prefilter_stats(st, 0)
+log('prefilter stats [viol, checked, slack, survivors, generated]', [int(v) for v in st])
