@@ -26,6 +26,7 @@
 // workgroups gives identical sums.
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int PF_K = 48;        // halfs per operand row (96 B)
 constexpr int PF_PITCH = 56;    // halfs per LDS row (112 B = 7 slots of 16 B: conflict-free ds_read_b128)
-constexpr int PF_ROWS = 128;    // pairs per LDS stage (4 MFMA row tiles)
+constexpr int PF_ROWS = 192;    // pairs per LDS stage (6 MFMA row tiles)
 constexpr int PF_NG = 2;        // 32-hypothesis groups per wave (LDS fragments are reused NG times)
 constexpr int PF_HYP = 4 * 32 * PF_NG;  // hypotheses per workgroup
 constexpr float PF_SMAX = 128.0f;       // point norm above which a problem bypasses the prefilter
@@ -414,50 +415,71 @@ __device__ __forceinline__ void split16(double v, _Float16* hi, _Float16* lo) {
   *lo = (_Float16)(v - (double)h);
 }
 
-__global__ void k_ransac_prob_of(const RansacProb* __restrict__ probs, int32_t* __restrict__ prob_of) {
-  const RansacProb pr = probs[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pr.m; i += gridDim.x * blockDim.x)
-    prob_of[pr.off + i] = blockIdx.y;
-}
+// rows of problem p in the f16 pair image: m rounded up to whole LDS stages
+__host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_ROWS - 1) / PF_ROWS * PF_ROWS; }
 
-// pair side: row = [bh(0..15) | bl(0..15) | bh(1..15), 0];  smax[p] = largest point norm of problem p
-__global__ void k_ransac_pack16(const float* __restrict__ src, const float* __restrict__ tgt,
-                                const int32_t* __restrict__ prob_of, int64_t n,
-                                _Float16* __restrict__ B16, unsigned* __restrict__ smax_bits) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-  const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
-  const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
-  double b[16];
-  b[0] = ss + qq;
-  b[1] = sx; b[2] = sy; b[3] = sz;
-  b[4] = qx * sx; b[5] = qx * sy; b[6] = qx * sz;
-  b[7] = qy * sx; b[8] = qy * sy; b[9] = qy * sz;
-  b[10] = qz * sx; b[11] = qz * sy; b[12] = qz * sz;
-  b[13] = qx; b[14] = qy; b[15] = qz;
-  _Float16 row[PF_K];
+// pair side: 112-B rows [bh(0..15) | bl(0..15) | bh(1..15), 0 | 8 x 0] in exactly the layout the
+// prefilter keeps in LDS (a stage is one contiguous 21-KiB copy); every problem is padded to whole
+// stages with rows whose d~^2 is +60000 (never counted).  smax[p] = largest point norm of problem p.
+// grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
+__global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restrict__ probs,
+                                                       const int64_t* __restrict__ off16,
+                                                       const float* __restrict__ src,
+                                                       const float* __restrict__ tgt,
+                                                       _Float16* __restrict__ B16,
+                                                       unsigned* __restrict__ smax_bits) {
+  __shared__ float red[4];
+  const RansacProb pr = probs[blockIdx.y];
+  const int mpad = (int)pf_padded(pr.m);
+  float mx = 0.f;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < mpad; j += gridDim.x * blockDim.x) {
+    union {
+      _Float16 h[PF_PITCH];
+      uint4 v[7];
+    } row;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    _Float16 hi, lo;
-    split16(b[k], &hi, &lo);
-    row[k] = hi;
-    row[16 + k] = lo;
-    if (k) row[31 + k] = hi;
+    for (int k = 0; k < 7; ++k) row.v[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (j < pr.m) {
+      const int64_t i = pr.off + j;
+      const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+      const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
+      const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
+      double b[16];
+      b[0] = ss + qq;
+      b[1] = sx; b[2] = sy; b[3] = sz;
+      b[4] = qx * sx; b[5] = qx * sy; b[6] = qx * sz;
+      b[7] = qy * sx; b[8] = qy * sy; b[9] = qy * sz;
+      b[10] = qz * sx; b[11] = qz * sy; b[12] = qz * sz;
+      b[13] = qx; b[14] = qy; b[15] = qz;
+      // 1.0000002: the f32 norm may round down
+      float mag = 1.0000002f * (float)sqrt(fmax(ss, qq));
+      // out of f16 range (or NaN): a finite (zero) row; smax then marks the problem's hypotheses unusable
+      const bool ok = mag <= PF_SMAX;
+      if (!(mag == mag)) mag = INFINITY;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
+        if (ok) split16(b[k], &hi, &lo);
+        row.h[k] = hi;
+        row.h[16 + k] = lo;
+        if (k) row.h[31 + k] = hi;
+      }
+      mx = fmaxf(mx, mag);
+    } else {
+      row.h[0] = (_Float16)60000.0f;  // pairs with a_0 = 1
+    }
+    uint4* dst = reinterpret_cast<uint4*>(B16 + (off16[blockIdx.y] + j) * PF_PITCH);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dst[k] = row.v[k];
   }
-  row[47] = (_Float16)0.0f;
-  uint4* dst = reinterpret_cast<uint4*>(B16 + i * PF_K);
-  const uint4* r4 = reinterpret_cast<const uint4*>(row);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) dst[k] = r4[k];
-  // 1.0000002: the f32 norm below may round down
-  const float mag = 1.0000002f * (float)sqrt(fmax(ss, qq));
-  if (!(mag <= PF_SMAX)) {  // out of f16 range (or NaN): a finite (zero) row; the problem's
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);  // hypotheses all become "unusable" via smax
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dst[k] = z;
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (mx > 0.f) atomicMax(&smax_bits[blockIdx.y], __float_as_uint(mx));  // non-negative floats order like uints
   }
-  atomicMax(&smax_bits[prob_of[i]], __float_as_uint(mag));  // non-negative floats order like uints
 }
 
 // hypothesis side: row = [ah(0..15) | ah(0..15) | al(1..15), 0] and the accumulator input
@@ -511,40 +533,71 @@ __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float
   bool usable = smax <= (double)PF_SMAX && tn <= 4.0 * (double)PF_SMAX && dev < 1.0e-3;
 #pragma unroll
   for (int k = 0; k < 16; ++k) usable = usable && fabs(a[k]) < 6.0e4;  // false for NaN
-  _Float16 row[PF_K];
+  union {
+    _Float16 h[PF_K];
+    uint4 v[6];
+  } row;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
     if (usable) split16(a[k], &hi, &lo);
-    row[k] = hi;
-    row[16 + k] = hi;
-    if (k) row[31 + k] = lo;
+    row.h[k] = hi;
+    row.h[16 + k] = hi;
+    if (k) row.h[31 + k] = lo;
   }
-  row[47] = (_Float16)0.0f;
+  row.h[47] = (_Float16)0.0f;
   uint4* dst = reinterpret_cast<uint4*>(A16 + ((int64_t)p * bmax + h) * PF_K);
-  const uint4* r4 = reinterpret_cast<const uint4*>(row);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) dst[k] = r4[k];
+  for (int k = 0; k < 6; ++k) dst[k] = row.v[k];
   const double w = 2.0 * smax + tn;
   const double eps = 1.2e-4 * w * w + 1.0e-5 + 3.0 * dev * smax * smax;
   // rounded towards -inf so that the f32 value never tightens the test
   c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - ((double)thr2 + eps)) : -INFINITY;
 }
 
-// Upper bounds of the inlier counts.  grid: x = hypothesis tile (PF_HYP) * splits, y = problem.
+// Upper bounds of the inlier counts.
+// grid: 1-D, 8 * slots * tiles * splits workgroups.  Workgroups are dealt round-robin to the 8 XCDs, so
+// XCD x = id % 8 is given the problems xcd_prob[x][0..slots) (host: longest-first balancing): all
+// workgroups that stream one problem's pair image run on ONE XCD at about the same time and share it
+// through that XCD's 4-MiB L2 instead of each pulling it from HBM / Infinity Cache.
 // MFMA operand maps (v_mfma_f32_32x32x16_f16): lane l supplies A[row l&31][k = 8(l>>5) .. +8) and
-// B[k = 8(l>>5) .. +8)][col l&31]; D as for the f32 shape.  rows = pairs (LDS), cols = hypotheses
-// (registers, PF_NG groups per wave).
+// B[k = 8(l>>5) .. +8)][col l&31]; D as for the f32 shape.  rows = pairs (LDS, shared by the four
+// waves), cols = hypotheses (registers, PF_NG groups of 32 per wave).
+//
+// Staging: a stage is PF_ROWS rows = 21 KiB, contiguous in the pair image, copied global -> LDS by
+// 21 LDS-DMA instructions of 1 KiB (global_load_lds_dwordx4: no staging registers, no ds_write); the
+// copy of stage s+1 is in flight while stage s is computed.
+//
+// Inner loop: units k = (row tile t, hypothesis group g), 12 per stage.  The three MFMAs of unit k are
+// issued interleaved with the sign extraction (16 x v_alignbit into a per-lane history word, one VALU
+// op per pair) of unit k-2, held in another of three rotating accumulator sets: a result is first
+// read a whole unit (>= 96 cycles) after the MFMA that wrote it, beyond the 11 wait states the
+// hardware requires.  The unit is one asm block: the compiler's scheduler does not keep this order
+// (it hoists the dependent VALU ops and pays s_nop 10 per unit).
 __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __restrict__ probs,
+                                                          const int64_t* __restrict__ off16,
                                                           const _Float16* __restrict__ B16,
                                                           const _Float16* __restrict__ A16,
                                                           const float* __restrict__ c_h, int it0,
                                                           int bcount, int bmax, int splits,
-                                                          int32_t* __restrict__ cnt_up) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[2][PF_ROWS * PF_PITCH];
-  const int p = blockIdx.y;
-  const int tile = blockIdx.x / splits;
-  const int split = blockIdx.x - tile * splits;
+                                                          const int32_t* __restrict__ xcd_prob,
+                                                          int slots, int tiles,
+                                                          int32_t* __restrict__ cnt_up,
+                                                          unsigned long long* __restrict__ trace) {
+  const unsigned long long t_start = trace ? wall_clock64() : 0ULL;
+  const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ULL;
+  constexpr int STAGE_BYTES = PF_ROWS * PF_PITCH * 2;  // 21504
+  constexpr int STAGE_KIB = STAGE_BYTES / 1024;        // 21 LDS-DMA instructions
+  static_assert(STAGE_BYTES % 1024 == 0, "a stage must be whole 1-KiB LDS-DMA instructions");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+  const int xcd = blockIdx.x & 7;
+  const int item = blockIdx.x >> 3;
+  const int slot = item / (tiles * splits);
+  const int inner = item - slot * (tiles * splits);
+  const int p = xcd_prob[xcd * slots + slot];
+  if (p < 0) return;
+  const int tile = inner / splits;
+  const int split = inner - tile * splits;
   const RansacProb pr = probs[p];
   if (pr.done) return;
   if (it0 + tile * PF_HYP >= pr.est_k || tile * PF_HYP >= bcount) return;
@@ -561,7 +614,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
   for (int g = 0; g < PF_NG; ++g) {
     // hypotheses past the chunk / bound read a valid row; their result is not stored
     int hh = h0 + 32 * g + col;
-    if (hh >= bcount || it0 + hh >= pr.est_k) hh = h0;
+    if (hh >= bcount || it0 + hh >= pr.est_k) hh = wave_live ? h0 : 0;
     const _Float16* row = A16 + ((int64_t)p * bmax + hh) * PF_K + 8 * half;
 #pragma unroll
     for (int m = 0; m < 3; ++m) bop[g][m] = *reinterpret_cast<const f16x8*>(row + 16 * m);
@@ -570,9 +623,10 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
     for (int r = 0; r < 16; ++r) cin[g][r] = c;
     asm volatile("" : "+v"(cin[g]));  // keep the 16 copies resident instead of re-splatting per tile
   }
-  const int per = ((pr.m + splits - 1) / splits + PF_ROWS - 1) / PF_ROWS * PF_ROWS;
+  const int mpad = (int)pf_padded(pr.m);
+  const int per = ((mpad / PF_ROWS + splits - 1) / splits) * PF_ROWS;
   const int beg = split * per;
-  const int end = min(pr.m, beg + per);
+  const int end = min(mpad, beg + per);
   unsigned bits[PF_NG];
   int cnt[PF_NG];
 #pragma unroll
@@ -580,64 +634,123 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
     bits[g] = 0u;
     cnt[g] = 0;
   }
-
-  // staging: 128 rows x 96 B per stage, 48 B per thread (row = tid / 2, half row = tid % 2)
-  uint4 stg[3];
-  const int s_row = tid >> 1, s_part = tid & 1;
-  auto stage_load = [&](int base) {
-    const int i = base + s_row;
-    const int64_t g = pr.off + (i < end ? i : 0);
-    const uint4* src = reinterpret_cast<const uint4*>(B16 + g * PF_K + 24 * s_part);
-    stg[0] = src[0];
-    stg[1] = src[1];
-    stg[2] = src[2];
-  };
-  auto stage_store = [&](int b, int base) {
-    if (base + s_row >= end) {  // padding row: d~^2 = 60000 + c_h, positive for every usable hypothesis
-      stg[0] = make_uint4(s_part == 0 ? 0x7b53u : 0u, 0u, 0u, 0u);  // f16 60000 in element 0 (a_0 = 1)
-      stg[1] = make_uint4(0u, 0u, 0u, 0u);
-      stg[2] = make_uint4(0u, 0u, 0u, 0u);
+  const char* gsrc = reinterpret_cast<const char*>(B16 + off16[p] * PF_PITCH) + lane * 16;
+  auto issue_stage = [&](int b, int base) {
+    const char* g = gsrc + (int64_t)base * (PF_PITCH * 2);
+#pragma unroll
+    for (int i = 0; i < (STAGE_KIB + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;  // wave-uniform
+      if (piece < STAGE_KIB)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(g + piece * 1024),
+            (__attribute__((address_space(3))) void*)(lds + b * STAGE_BYTES + piece * 1024), 16, 0, 0);
     }
-    uint4* dst = reinterpret_cast<uint4*>(&lds[b][s_row * PF_PITCH + 24 * s_part]);
-    dst[0] = stg[0];
-    dst[1] = stg[1];
-    dst[2] = stg[2];
   };
-  if (beg < end) {
-    stage_load(beg);
-    stage_store(0, beg);
+  static_assert(PF_NG == 2 && PF_ROWS == 192, "the unrolled schedule below is written for 12 units per stage");
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 S0, S1 = zero16, S2 = zero16;  // +0: the first two (dummy) extractions shift in zeros
+#define PF_UNIT(DST, SRC, G, A, COUNT) \
+  asm volatile( \
+      "v_mfma_f32_32x32x16_f16 %0, %2, %5, %8\n\t" \
+      "v_alignbit_b32 %1, %1, %9, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %10, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %11, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %12, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %13, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %14, 31\n\t" \
+      "v_mfma_f32_32x32x16_f16 %0, %3, %6, %0\n\t" \
+      "v_alignbit_b32 %1, %1, %15, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %16, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %17, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %18, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %19, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %20, 31\n\t" \
+      "v_mfma_f32_32x32x16_f16 %0, %4, %7, %0\n\t" \
+      "v_alignbit_b32 %1, %1, %21, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %22, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %23, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %24, 31" \
+      : "=&v"(DST), "+v"(bits[G]) \
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(bop[G][0]), "v"(bop[G][1]), "v"(bop[G][2]), \
+        "v"(cin[G]), "v"(SRC[0]), "v"(SRC[1]), "v"(SRC[2]), "v"(SRC[3]), "v"(SRC[4]), "v"(SRC[5]), \
+        "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
+        "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15])); \
+  if (COUNT) cnt[G] += __popc(bits[G]);
+#define PF_LOAD(A, TILE)                                                                          \
+  {                                                                                               \
+    const _Float16* arow_ = reinterpret_cast<const _Float16*>(lds + buf * STAGE_BYTES) +          \
+                            ((TILE) * 32 + col) * PF_PITCH + 8 * half;                            \
+    _Pragma("unroll") for (int m = 0; m < 3; ++m) A[m] =                                          \
+        *reinterpret_cast<const f16x8*>(arow_ + 16 * m);                                          \
   }
+  if (beg < end) issue_stage(0, beg);
+  const unsigned long long t_loop = trace ? wall_clock64() : 0ULL;
+  unsigned long long t_wait_dma = 0, t_wait_bar = 0;
   int buf = 0;
   for (int base = beg; base < end; base += PF_ROWS) {
-    __syncthreads();
-    const bool more = base + PF_ROWS < end;
-    if (more) stage_load(base + PF_ROWS);
-    if (wave_live) {
-#pragma unroll
-      for (int t = 0; t < PF_ROWS / 32; ++t) {
-        const _Float16* arow = &lds[buf][(t * 32 + col) * PF_PITCH + 8 * half];
-        f16x8 a[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const f16x8*>(arow + 16 * m);
-#pragma unroll
-        for (int g = 0; g < PF_NG; ++g) {
-          __builtin_amdgcn_s_setprio(1);
-          f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bop[g][0], cin[g], 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bop[g][1], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bop[g][2], d, 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          // shift the 16 sign bits into the per-lane history word: one VALU op per pair
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            bits[g] = __builtin_amdgcn_alignbit(bits[g], __float_as_uint(d[r]), 31);
-          if (t & 1) cnt[g] += __popc(bits[g]);  // 32 fresh bits every second tile
-        }
-      }
+    // this wave's pieces of the stage have landed; after the barrier everybody's have, and everybody
+    // has finished reading the other buffer, which the next copy overwrites
+    const unsigned long long tw0 = trace ? wall_clock64() : 0ULL;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tw1 = trace ? wall_clock64() : 0ULL;
+    __builtin_amdgcn_s_barrier();
+    if (trace) {
+      const unsigned long long tw2 = wall_clock64();
+      t_wait_dma += tw1 - tw0;
+      t_wait_bar += tw2 - tw1;
     }
-    if (more) stage_store(buf ^ 1, base + PF_ROWS);
+    if (base + PF_ROWS < end) issue_stage(buf ^ 1, base + PF_ROWS);
+    if (wave_live) {
+      // unit k writes set k % 3 and extracts set (k + 1) % 3 = unit k-2 = (tile t-1, same group);
+      // 32 fresh sign bits are counted whenever tile t-1 is odd
+      f16x8 aX[3], aY[3];
+      PF_LOAD(aX, 0)
+      PF_LOAD(aY, 1)
+      PF_UNIT(S0, S1, 0, aX, true)
+      PF_UNIT(S1, S2, 1, aX, true)
+      PF_LOAD(aX, 2)
+      PF_UNIT(S2, S0, 0, aY, false)
+      PF_UNIT(S0, S1, 1, aY, false)
+      PF_LOAD(aY, 3)
+      PF_UNIT(S1, S2, 0, aX, true)
+      PF_UNIT(S2, S0, 1, aX, true)
+      PF_LOAD(aX, 4)
+      PF_UNIT(S0, S1, 0, aY, false)
+      PF_UNIT(S1, S2, 1, aY, false)
+      PF_LOAD(aY, 5)
+      PF_UNIT(S2, S0, 0, aX, true)
+      PF_UNIT(S0, S1, 1, aX, true)
+      PF_UNIT(S1, S2, 0, aY, false)
+      PF_UNIT(S2, S0, 1, aY, false)
+    }
     buf ^= 1;
   }
-  if (!wave_live) return;
+#undef PF_UNIT
+#undef PF_LOAD
+  if (trace && lane == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+    o[0] = t_start;
+    o[1] = (t_wait_dma << 32) | t_wait_bar;
+    o[2] = wall_clock64();
+    // shader-clock cycles of this wave's lifetime in the top bits (with o[2] - o[0] at 100 MHz: the
+    // in-kernel clock), placement in the low bits
+    o[3] = ((__builtin_amdgcn_s_memtime() - c_start) << 24) | ((unsigned long long)(xcc & 0xf) << 20) |
+           (hwid & 0xfffff);
+    (void)t_loop;
+  }
+  if (!wave_live || beg >= end) return;
+  // drain: the asm blocks hide their MFMAs from the compiler's hazard recognizer
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S1), "+v"(S2));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bits[0] = __builtin_amdgcn_alignbit(bits[0], __float_as_uint(S1[r]), 31);
+  cnt[0] += __popc(bits[0]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bits[1] = __builtin_amdgcn_alignbit(bits[1], __float_as_uint(S2[r]), 31);
+  cnt[1] += __popc(bits[1]);
 #pragma unroll
   for (int g = 0; g < PF_NG; ++g) {
     const int c = cnt[g] + __shfl_xor(cnt[g], 32);
@@ -938,17 +1051,25 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   CS_REQUIRE(probs.p && pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p && n_active.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   const bool pf_alloc = use_pf && max_iter > pf_from;
-  PoolBuf<_Float16> B16(pf_alloc ? (size_t)tot1 * PF_K : 8), A16(pf_alloc ? (size_t)n_prob * bmax * PF_K : 8);
+  // f16 pair image: every problem padded to whole LDS stages
+  std::vector<int64_t> h_off16(n_prob + 1, 0);
+  for (int p = 0; p < n_prob; ++p) h_off16[p + 1] = h_off16[p] + pf_padded(hp[p].m);
+  const int64_t rows16 = h_off16[n_prob] ? h_off16[n_prob] : 1;
+  PoolBuf<_Float16> B16(pf_alloc ? (size_t)rows16 * PF_PITCH : 8), A16(pf_alloc ? (size_t)n_prob * bmax * PF_K : 8);
+  PoolBuf<int64_t> off16(n_prob + 1);
   PoolBuf<float> c_h(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
-  PoolBuf<int32_t> n_surv(n_prob), prob_of(pf_alloc ? (size_t)tot1 : 1);
+  PoolBuf<int32_t> n_surv(n_prob);
   PoolBuf<unsigned> smax_bits(n_prob);
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
-  CS_REQUIRE(B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && n_surv.p && prob_of.p && smax_bits.p &&
+  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && n_surv.p && smax_bits.p &&
                  exact_dbg.p && chk_stats.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
-  std::vector<int32_t> h_surv(n_prob);
+  std::vector<int32_t> h_surv(n_prob), h_xcd;
+  int pslots = 1;
+  PoolBuf<int32_t> xcd_prob((size_t)8 * n_prob);
+  CS_REQUIRE(xcd_prob.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   CS_HIP_CHECK(hipMemcpyAsync(probs.p, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
@@ -959,10 +1080,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   if (pf_alloc) {
     CS_HIP_CHECK(hipMemsetAsync(smax_bits.p, 0, sizeof(unsigned) * n_prob, s));
     CS_HIP_CHECK(hipMemsetAsync(chk_stats.p, 0, sizeof(unsigned long long) * 4, s));
-    hipLaunchKernelGGL(k_ransac_prob_of, dim3((unsigned)ceil_div(m_max > 0 ? m_max : 1, 256), (unsigned)n_prob),
-                       dim3(256), 0, s, probs.p, prob_of.p);
-    hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
-                       d_src, d_tgt, prob_of.p, total, B16.p, smax_bits.p);
+    int pblocks = (int)ceil_div(m_max > 0 ? m_max : 1, 256);
+    if (pblocks > 64) pblocks = 64;
+    CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
+                                hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
+                       probs.p, off16.p, d_src, d_tgt, B16.p, smax_bits.p);
     CS_LAUNCH_CHECK();
   }
   // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
@@ -972,6 +1095,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const float scale = ldexpf(1.0f, 31 - ex);
   const double log_1mc = log(1.0 - confidence);  // -inf when confidence == 1: never exits early
   unsigned long long st_surv = 0, st_eval = 0;
+  const int trace_it0 = getenv("CS_PF_TRACE") ? atoi(getenv("CS_PF_TRACE")) : -1;
+  PoolBuf<unsigned long long> trace(trace_it0 >= 0 ? (size_t)8 * n_prob * 64 * 16 * 16 : 1);
+  size_t trace_n = 0;
+  if (trace_it0 >= 0) CS_HIP_CHECK(hipMemsetAsync(trace.p, 0, sizeof(unsigned long long) * (size_t)8 * n_prob * 64 * 16 * 16, s));
 
   int it0 = 0;
   while (it0 < max_iter) {
@@ -1013,10 +1140,38 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                          res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
       const int ptiles = (b + PF_HYP - 1) / PF_HYP;
-      int psplits = (int)(2048 / ((int64_t)n_prob * ptiles));
+      // deal the live problems to the 8 XCDs, longest first onto the least loaded XCD
+      int live = 0;
+      {
+        std::vector<int> order;
+        for (int p = 0; p < n_prob; ++p)
+          if (!hp[p].done && hp[p].est_k > it0) order.push_back(p);
+        live = (int)order.size();
+        std::sort(order.begin(), order.end(), [&](int a, int c) { return hp[a].m > hp[c].m; });
+        std::vector<std::vector<int>> lists(8);
+        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p : order) {
+          int best = 0;
+          for (int x = 1; x < 8; ++x)
+            if (load[x] < load[best]) best = x;
+          lists[best].push_back(p);
+          load[best] += pf_padded(hp[p].m);
+        }
+        pslots = 0;
+        for (int x = 0; x < 8; ++x) pslots = std::max(pslots, (int)lists[x].size());
+        if (pslots < 1) pslots = 1;
+        h_xcd.assign((size_t)8 * pslots, -1);
+        for (int x = 0; x < 8; ++x)
+          for (size_t i = 0; i < lists[x].size(); ++i) h_xcd[(size_t)x * pslots + i] = lists[x][i];
+      }
+      CS_HIP_CHECK(hipMemcpyAsync(xcd_prob.p, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
+                                  hipMemcpyHostToDevice, s));
+      // 768 workgroups are resident (3 per CU): split the pair range until there are >= 8 rounds of
+      // workgroups, as long as a workgroup keeps >= 8 stages
+      int psplits = (int)((8 * 768 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
       if (psplits < 1) psplits = 1;
       if (psplits > 16) psplits = 16;
-      while (psplits > 1 && m_max / psplits < 2 * PF_ROWS) --psplits;
+      while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
                          0, s, probs.p, hyp.p, smax_bits.p, it0, b, bmax, thr2, A16.p, c_h.p);
       CS_HIP_CHECK(hipMemsetAsync(n_surv.p, 0, sizeof(int32_t) * n_prob, s));
@@ -1026,9 +1181,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       {
         // 94 FLOP per (hypothesis, pair): the 47 multiply-adds of the hi/lo expansion
         ProfScope prof("ransac_pre", s, 94.0 * eval_pairs);
-        hipLaunchKernelGGL(k_ransac_prefilter, dim3((unsigned)(ptiles * psplits), (unsigned)n_prob),
-                           dim3(256), 0, s, probs.p, B16.p, A16.p, c_h.p, it0, b, bmax, psplits,
-                           cnt_up.p);
+        const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
+        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, probs.p, off16.p, B16.p,
+                           A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob.p, pslots, ptiles, cnt_up.p,
+                           (trace_it0 == it0) ? trace.p : nullptr);
+        if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
                          dim3(256), 0, s, probs.p, cnt_up.p, it0, b, bmax, res_cnt.p, hlist.p, n_surv.p);
@@ -1074,6 +1231,15 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         if (!prev[p].done) st_surv += (unsigned long long)h_surv[p];
     it0 += b;
     if (h_active == 0) break;
+  }
+  if (trace_n) {
+    std::vector<unsigned long long> ht(trace_n);
+    CS_HIP_CHECK(hipMemcpy(ht.data(), trace.p, sizeof(unsigned long long) * trace_n, hipMemcpyDeviceToHost));
+    FILE* f = fopen(getenv("CS_PF_TRACE_FILE") ? getenv("CS_PF_TRACE_FILE") : "/tmp/pf_trace.bin", "wb");
+    if (f) {
+      fwrite(ht.data(), sizeof(unsigned long long), trace_n, f);
+      fclose(f);
+    }
   }
   g_pf_stats[3] += st_surv;
   g_pf_stats[4] += st_eval;

@@ -1,6 +1,6 @@
 """Where does the host spend time between GPU launches in one bench step? (line-level timers)"""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from corsair_amd import harness, synth, registration as R, backend as B
 dev = torch.device('cuda:0')

@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     disp[k].add(r["Dispatch_Id"])
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
-    if not k.startswith(("cs::", "void cs::")):
+    if not k.startswith(("cs::", "void cs::", "_ZN2cs")):
         continue
     n = len(disp[k])
     print(f"{k:50s} launches={n:5d} " + " ".join(f"{c}={x:.4g} (per launch {x/n:.4g})" for c, x in v.items()))

@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from corsair_amd import _lib, harness, synth, backend as B, registration as R
 def log(*a):
