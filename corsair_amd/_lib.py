@@ -12,7 +12,8 @@ import re
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcorsair_hip.so")
+# CORSAIR_HIP_LIB points diagnostics at an alternative build of the same library
+LIB_PATH = os.environ.get("CORSAIR_HIP_LIB") or os.path.join(_HERE, "csrc", "libcorsair_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "corsair_hip.h")
 
 _lib = None

@@ -10,6 +10,8 @@
 // once per query tile).
 #include <stdlib.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include <vector>
 
 #include "common.h"
@@ -120,6 +122,286 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
       out_idx[orow * k + j] = ij;
       if (out_dist) out_dist[orow * k + j] = ij >= 0 ? sqrt(dj) : INFINITY;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// feature k-NN on the f64 matrix pipe (16-d features, the registration path's shape).
+// dist(q, t) = |q|^2 + |t|^2 - 2 q.t with the dot products on v_mfma_f64_16x16x4_f64: the VALU is left
+// with 3 f64 ops per pair instead of 32.  The expansion rounds differently from the canonical chain,
+// so it only SHORTLISTS: every lane keeps the KNM_KK best rows of its quarter of the targets by the
+// expanded distance, k_knn_rescore re-evaluates the 4 x KNM_KK candidates of a query with the
+// canonical chain sum_c (q_c - t_c)^2 and ranks them by (distance, row).  The result equals the exact
+// kernel's unless more than KNM_KK - k rows of one quarter tie with the k-th neighbour to within the
+// rounding of the expansion (~1e-15 relative) -- the caveat every f64 distance-matrix method has.
+// Labelled searches (part-to-part correspondences): the targets of a segment are visited in label
+// order (stable), so a wave skips the 16-row tiles whose labels cannot match its 16 queries.
+// ------------------------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int KNM_NG = 1;               // 16-query groups per wave (each A fragment is used NG times)
+constexpr int KNM_QT = 64 * KNM_NG;     // queries per workgroup
+constexpr int KNM_TT = 256;             // target rows per LDS stage (one row per thread)
+constexpr int KNM_PITCH = 18;           // floats per LDS row: conflict-free ds_read_b32 of the A fragments
+constexpr int KNM_KK = 8;               // shortlist per lane (k <= KNM_KK - 2)
+constexpr int KNM_PEND = 4;             // pending (not yet ranked) candidates per lane
+
+__global__ void k_seg_keys(const int64_t* __restrict__ off, int n_seg, const int32_t* __restrict__ label,
+                           uint32_t* __restrict__ keys, int32_t* __restrict__ rows) {
+  const int sg = blockIdx.y;
+  const int64_t b = off[sg], e = off[sg + 1];
+  for (int64_t i = b + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = label[i];
+    keys[i] = (uint32_t)sg * 16u + (uint32_t)((l >= 0 && l < 8) ? l : 8);
+    rows[i] = (int32_t)(i - b);  // row local to the segment
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ work,
+                                                    const float* __restrict__ qf,
+                                                    const float* __restrict__ tf,
+                                                    const double* __restrict__ qnorm,
+                                                    const double* __restrict__ tnorm,
+                                                    const int32_t* __restrict__ qlabel,
+                                                    const int32_t* __restrict__ tlabel,
+                                                    const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ torder,
+                                                    int32_t* __restrict__ cand_i) {
+  // double-buffered stage: features (f32, converted when the fragment is read), |t|^2, label, row id
+  __shared__ float t_lds[2][KNM_TT * KNM_PITCH];
+  __shared__ double tn_lds[2][KNM_TT];
+  __shared__ int32_t tl_lds[2][KNM_TT];
+  __shared__ int32_t ti_lds[2][KNM_TT];
+  const KnnWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;  // query within a group (B side); target row within a 16-row tile (A side)
+  const int kq = lane >> 4;   // k slot of the operands; row group of the results
+  const bool use_labels = qlabel != nullptr;
+  double qb[KNM_NG][4], my_qn[KNM_NG];
+  int want[KNM_NG];
+  bool qvalid[KNM_NG];
+  int wmin = 0x7fffffff, wmax = -2;
+#pragma unroll
+  for (int g = 0; g < KNM_NG; ++g) {
+    const int qloc = wave * 16 * KNM_NG + 16 * g + col;
+    qvalid[g] = qloc < wk.qn;
+    const int64_t qrow = wk.q0 + (qvalid[g] ? qloc : 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qb[g][s4] = (double)qf[qrow * 16 + 4 * s4 + kq];  // B[k = 4 s + kq][query]
+    my_qn[g] = qnorm[qrow];
+    want[g] = -1;
+    if (use_labels) {
+      const int ql = qlabel[qrow];
+      want[g] = (qvalid[g] && ql >= 0 && ql < 8) ? perm[wk.prob * 8 + ql] : -2;
+      if (want[g] >= 0) wmin = min(wmin, want[g]);
+      wmax = max(wmax, want[g]);
+    }
+  }
+  // label window of the wave's queries (tile skipping)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    wmin = min(wmin, __shfl_xor(wmin, off));
+    wmax = max(wmax, __shfl_xor(wmax, off));
+  }
+  // Ranked shortlist (ascending) plus a small unranked pending list per lane.  A candidate below the
+  // lane's threshold is only appended (a register shift); the pending lists of the whole wave are
+  // ranked together when one of them is full.  Ranking on every hit would run the 8-slot insertion
+  // for nearly every element, because some lane of the 64 almost always has a hit.
+  double bd[KNM_NG][KNM_KK], pd[KNM_NG][KNM_PEND];
+  int32_t bi[KNM_NG][KNM_KK], pi[KNM_NG][KNM_PEND];
+  int pn[KNM_NG];
+#pragma unroll
+  for (int g = 0; g < KNM_NG; ++g) {
+    pn[g] = 0;
+#pragma unroll
+    for (int j = 0; j < KNM_KK; ++j) {
+      bd[g][j] = INFINITY;
+      bi[g][j] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int j = 0; j < KNM_PEND; ++j) {
+      pd[g][j] = INFINITY;
+      pi[g][j] = 0x7fffffff;
+    }
+  }
+  auto rank_pending = [&](int g) {
+#pragma unroll
+    for (int e = 0; e < KNM_PEND; ++e) {
+      double cd = pd[g][e];  // +inf in unused slots: never inserted
+      int32_t ci = pi[g][e];
+      pd[g][e] = INFINITY;
+      if (cd < bd[g][KNM_KK - 1]) {
+        bool carry = false;
+#pragma unroll
+        for (int s2 = 0; s2 < KNM_KK; ++s2) {
+          if (carry || cd < bd[g][s2]) {
+            carry = true;
+            const double td = bd[g][s2];
+            const int32_t ti = bi[g][s2];
+            bd[g][s2] = cd;
+            bi[g][s2] = ci;
+            cd = td;
+            ci = ti;
+          }
+        }
+      }
+    }
+    pn[g] = 0;
+  };
+  // staging registers: thread tid owns row tid of the stage
+  float4 sf[4];
+  double sn;
+  int32_t sl, si;
+  auto stage_load = [&](int tbase) {
+    const int j = tid;
+    const bool ok = tbase + j < wk.tn;
+    const int src = ok ? (torder ? torder[wk.t0 + tbase + j] : tbase + j) : 0;
+    const float4* rp = reinterpret_cast<const float4*>(tf + (wk.t0 + src) * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sf[c] = rp[c];
+    sn = ok ? tnorm[wk.t0 + src] : INFINITY;  // +inf distance for rows past the segment
+    const int tl = (ok && use_labels) ? tlabel[wk.t0 + src] : (ok ? 0 : 8);
+    sl = (tl >= 0 && tl < 8) ? tl : 8;         // 8 = no part: matches no query, sorts last
+    si = ok ? src : 0x7fffffff;
+  };
+  auto stage_store = [&](int b) {
+    float2* dst = reinterpret_cast<float2*>(&t_lds[b][tid * KNM_PITCH]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dst[2 * c] = make_float2(sf[c].x, sf[c].y);
+      dst[2 * c + 1] = make_float2(sf[c].z, sf[c].w);
+    }
+    tn_lds[b][tid] = sn;
+    tl_lds[b][tid] = sl;
+    ti_lds[b][tid] = si;
+  };
+  if (wk.tn > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int tbase = 0; tbase < wk.tn; tbase += KNM_TT) {
+    const int tcount = min(KNM_TT, wk.tn - tbase);
+    const bool more = tbase + KNM_TT < wk.tn;
+    if (more) stage_load(tbase + KNM_TT);  // global loads in flight during the tiles below
+    for (int t = 0; t < (tcount + 15) / 16; ++t) {
+      if (use_labels) {
+        // label order: the tile's labels span [first, last]
+        const int l0 = tl_lds[buf][16 * t], l1 = tl_lds[buf][min(16 * t + 15, tcount - 1)];
+        if (l1 < wmin || l0 > wmax) continue;  // wave-uniform
+      }
+      const float* ap = &t_lds[buf][(16 * t + col) * KNM_PITCH + kq];
+      double a[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) a[s4] = (double)ap[4 * s4];  // A[target row][k = 4 s + kq]
+      double tn4[4];
+      int tl4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tn4[r] = tn_lds[buf][16 * t + kq + 4 * r];
+        tl4[r] = tl_lds[buf][16 * t + kq + 4 * r];
+      }
+#pragma unroll
+      for (int g = 0; g < KNM_NG; ++g) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], qb[g][s4], acc, 0, 0, 0);
+        // acc[r] = dot(target row 16 t + kq + 4 r, query col of group g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double dist = fma(-2.0, acc[r], my_qn[g] + tn4[r]);
+          if (use_labels && tl4[r] != want[g]) dist = INFINITY;
+          if (dist < bd[g][KNM_KK - 1]) {
+#pragma unroll
+            for (int e = KNM_PEND - 1; e > 0; --e) {
+              pd[g][e] = pd[g][e - 1];
+              pi[g][e] = pi[g][e - 1];
+            }
+            pd[g][0] = dist;
+            pi[g][0] = ti_lds[buf][16 * t + kq + 4 * r];
+            ++pn[g];
+          }
+          if (__any(pn[g] == KNM_PEND)) rank_pending(g);
+        }
+      }
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int g = 0; g < KNM_NG; ++g) {
+    rank_pending(g);
+    const int qloc = wave * 16 * KNM_NG + 16 * g + col;
+    if (qvalid[g]) {
+      const int64_t base = ((wk.o0 + qloc) * 4 + kq) * KNM_KK;
+#pragma unroll
+      for (int j = 0; j < KNM_KK; ++j) cand_i[base + j] = bi[g][j];
+    }
+  }
+}
+
+// One thread per query: canonical distances of its 4 * KNM_KK candidates, k best by (distance, row).
+__global__ void k_knn_rescore16(const KnnWork* __restrict__ work, const float* __restrict__ qf,
+                                const float* __restrict__ tf, const int32_t* __restrict__ cand_i,
+                                int k, int32_t* __restrict__ out_idx, double* __restrict__ out_dist) {
+  const KnnWork wk = work[blockIdx.x];
+  const int qloc = threadIdx.x;
+  if (qloc >= wk.qn) return;
+  const int64_t qrow = wk.q0 + qloc;
+  double q[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) q[c] = (double)qf[qrow * 16 + c];
+  double bd[KNN_MAXK];
+  int32_t bi[KNN_MAXK];
+#pragma unroll
+  for (int j = 0; j < KNN_MAXK; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+  const int32_t* ci = cand_i + (wk.o0 + qloc) * 4 * KNM_KK;
+  for (int c = 0; c < 4 * KNM_KK; ++c) {
+    const int32_t row = ci[c];
+    if (row == 0x7fffffff) continue;
+    const float* tp = tf + (wk.t0 + row) * 16;
+    double d = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double diff = q[e] - (double)tp[e];
+      d = fma(diff, diff, d);
+    }
+    // ordered insertion by (d, row)
+    double cd = d;
+    int32_t cr = row;
+    bool carry = false;
+#pragma unroll
+    for (int s2 = 0; s2 < KNN_MAXK; ++s2) {
+      if (carry || cd < bd[s2] || (cd == bd[s2] && cr < bi[s2])) {
+        carry = true;
+        const double td = bd[s2];
+        const int32_t ti = bi[s2];
+        bd[s2] = cd;
+        bi[s2] = cr;
+        cd = td;
+        cr = ti;
+      }
+    }
+  }
+  const int64_t orow = wk.o0 + qloc;
+  for (int j = 0; j < k; ++j) {
+    double dj = INFINITY;
+    int32_t ij = 0x7fffffff;
+#pragma unroll
+    for (int s2 = 0; s2 < KNN_MAXK; ++s2)
+      if (s2 == j) {
+        dj = bd[s2];
+        ij = bi[s2];
+      }
+    const bool have = ij != 0x7fffffff;
+    out_idx[orow * k + j] = have ? ij : -1;
+    if (out_dist) out_dist[orow * k + j] = have ? sqrt(dj) : INFINITY;
   }
 }
 
@@ -263,7 +545,6 @@ __global__ void k_topk_finish(const unsigned long long* carry_d, const int* carr
 // distances are those of the exact kernel unless more than `margin` catalog rows tie with the k-th
 // neighbour to within ~2e-15 -- the same caveat cdist itself has.
 // ------------------------------------------------------------------------------------------
-using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int TKM_QT = 64;     // queries per block (16 per wave)
 constexpr int TKM_XT = 64;     // catalog rows per tile
 constexpr int TKM_DC = 64;     // feature chunk in LDS
@@ -540,21 +821,29 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
              CS_ERR_INVALID, "cs_knn_feat: labels and perm must be given together");
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  // 16-d features with k <= KNM_KK - 2 go through the f64 matrix pipe (shortlist + canonical rescore);
+  // CS_KNN_MFMA=0 forces the all-VALU exact kernel
+  const char* env = getenv("CS_KNN_MFMA");
+  const bool mfma = dim == 16 && k <= KNM_KK - 2 && !(env && env[0] == '0');
+  const int qtile = mfma ? KNM_QT : 256;
   std::vector<KnnWork> work;
   int64_t out_row = 0;
+  int nqseg = 0, ntseg = 0;
   for (int p = 0; p < n_prob; ++p) {
     CS_REQUIRE(h_qseg[p] >= 0 && h_tseg[p] >= 0, CS_ERR_INVALID,
                "cs_knn_feat: negative segment id in problem %d", p);
+    nqseg = h_qseg[p] + 1 > nqseg ? h_qseg[p] + 1 : nqseg;
+    ntseg = h_tseg[p] + 1 > ntseg ? h_tseg[p] + 1 : ntseg;
     const int64_t q0 = h_qoff[h_qseg[p]], t0 = h_toff[h_tseg[p]];
     int64_t qn = h_qoff[h_qseg[p] + 1] - q0, tn = h_toff[h_tseg[p] + 1] - t0;
     CS_REQUIRE(qn >= 0 && tn >= 0 && tn < (1LL << 31), CS_ERR_INVALID,
                "cs_knn_feat: bad segment in problem %d", p);
-    for (int64_t q = 0; q < qn; q += 256) {
+    for (int64_t q = 0; q < qn; q += qtile) {
       KnnWork w;
       w.q0 = q0 + q;
       w.t0 = t0;
       w.o0 = out_row + q;
-      w.qn = (int32_t)(qn - q < 256 ? qn - q : 256);
+      w.qn = (int32_t)(qn - q < qtile ? qn - q : qtile);
       w.tn = (int32_t)tn;
       w.prob = p;
       w.pad = 0;
@@ -568,6 +857,55 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   if (rc) return rc;
   double knn_flop = 0.0;
   for (const KnnWork& w : work) knn_flop += 3.0 * (double)w.qn * (double)w.tn * (double)dim;
+  if (mfma) {
+    const int64_t nq_rows = h_qoff[nqseg], nt_rows = h_toff[ntseg];
+    CS_REQUIRE(nt_rows < (1LL << 31) && ntseg < (1 << 27), CS_ERR_UNSUPPORTED,
+               "cs_knn_feat: too many target rows / segments");
+    PoolBuf<double> qnorm((size_t)(nq_rows ? nq_rows : 1)), tnorm((size_t)(nt_rows ? nt_rows : 1));
+    PoolBuf<int32_t> cand((size_t)(out_row ? out_row : 1) * 4 * KNM_KK);
+    PoolBuf<int32_t> torder;
+    PoolBuf<uint32_t> keys, keys_sorted;
+    PoolBuf<int32_t> rows_in;
+    PoolBuf<int64_t> dtoff;
+    PoolBuf<char> tmp;
+    CS_REQUIRE(qnorm.p && tnorm.p && cand.p, CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+    if (nq_rows)
+      hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq_rows, 256)), dim3(256), 0, s, d_qf,
+                         nq_rows, 16, qnorm.p);
+    if (nt_rows)
+      hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nt_rows, 256)), dim3(256), 0, s, d_tf,
+                         nt_rows, 16, tnorm.p);
+    if (d_tlabel && nt_rows) {
+      // label order of every target segment (stable: equal labels keep their row order)
+      std::vector<int64_t> toff(h_toff, h_toff + ntseg + 1);
+      rc = upload(dtoff, toff, s);
+      if (rc) return rc;
+      CS_REQUIRE(torder.alloc((size_t)nt_rows) && keys.alloc((size_t)nt_rows) &&
+                     keys_sorted.alloc((size_t)nt_rows) && rows_in.alloc((size_t)nt_rows),
+                 CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      hipLaunchKernelGGL(k_seg_keys, dim3(16, (unsigned)ntseg), dim3(256), 0, s, dtoff.p, ntseg, d_tlabel,
+                         keys.p, rows_in.p);
+      int end_bit = 4;
+      while ((1LL << end_bit) < (int64_t)ntseg * 16) ++end_bit;
+      size_t tmp_bytes = 0;
+      CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, rows_in.p,
+                                                      torder.p, (int)nt_rows, 0, end_bit, s));
+      CS_REQUIRE(tmp.alloc(tmp_bytes ? tmp_bytes : 1), CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_sorted.p, rows_in.p,
+                                                      torder.p, (int)nt_rows, 0, end_bit, s));
+    }
+    {
+      ProfScope prof("knn", s, knn_flop);
+      hipLaunchKernelGGL(k_knn_mfma16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_qf, d_tf,
+                         qnorm.p, tnorm.p, d_qlabel, d_tlabel, d_perm, d_tlabel ? torder.p : nullptr,
+                         cand.p);
+      hipLaunchKernelGGL(k_knn_rescore16, dim3((unsigned)work.size()), dim3(KNM_QT), 0, s, dwork.p, d_qf,
+                         d_tf, cand.p, k, d_idx, d_dist);
+      CS_LAUNCH_CHECK();
+    }
+    CS_HIP_CHECK(hipStreamSynchronize(s));  // scratch returns to the pool
+    return CS_OK;
+  }
   {
     ProfScope prof("knn", s, knn_flop);
     dim3 grid((unsigned)work.size());

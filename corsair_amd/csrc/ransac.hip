@@ -126,9 +126,17 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
                                                     const float* __restrict__ src,
                                                     const float* __restrict__ tgt, int it0,
                                                     int bcount, int bmax, int ransac_n,
-                                                    uint64_t seed, float* __restrict__ hyp) {
-  const int p = blockIdx.y;
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    uint64_t seed,
+                                                    const int32_t* __restrict__ xcd_prob, int slots,
+                                                    int tiles, float* __restrict__ hyp) {
+  // 1-D grid dealt round-robin to the XCDs: XCD x samples only the problems xcd_prob[x][.], whose
+  // correspondences then stay in that XCD's L2 (the sampling is a random gather of 24-B rows)
+  const int xcd = blockIdx.x & 7;
+  const int item = blockIdx.x >> 3;
+  const int slot = item / tiles;
+  const int p = xcd_prob[xcd * slots + slot];
+  if (p < 0) return;
+  const int h = (item - slot * tiles) * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
   const RansacProb pr = probs[p];
   const int itr = it0 + h;
@@ -1112,10 +1120,37 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (splits < 1) splits = 1;
     if (splits > 16) splits = 16;
     while (splits > 1 && m_max / splits < 4 * RC_CHUNK) --splits;
+    // deal the live problems to the 8 XCDs, longest first onto the least loaded XCD
+    int live = 0;  // problems still iterating in this round
+    {
+      std::vector<int> order;
+      for (int p = 0; p < n_prob; ++p)
+        if (!hp[p].done && hp[p].est_k > it0) order.push_back(p);
+      live = (int)order.size();
+      std::sort(order.begin(), order.end(), [&](int a, int c) { return hp[a].m > hp[c].m; });
+      std::vector<std::vector<int>> lists(8);
+      int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p : order) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x)
+          if (load[x] < load[best]) best = x;
+        lists[best].push_back(p);
+        load[best] += pf_padded(hp[p].m);
+      }
+      pslots = 0;
+      for (int x = 0; x < 8; ++x) pslots = std::max(pslots, (int)lists[x].size());
+      if (pslots < 1) pslots = 1;
+      h_xcd.assign((size_t)8 * pslots, -1);
+      for (int x = 0; x < 8; ++x)
+        for (size_t i = 0; i < lists[x].size(); ++i) h_xcd[(size_t)x * pslots + i] = lists[x][i];
+    }
+    CS_HIP_CHECK(hipMemcpyAsync(xcd_prob.p, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
+                                hipMemcpyHostToDevice, s));
     {
       ProfScope prof("ransac_hyp", s);
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                         dim3(256), 0, s, probs.p, d_src, d_tgt, it0, b, bmax, ransac_n, seed, hyp.p);
+      const int htiles = (b + 255) / 256;
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, probs.p,
+                         d_src, d_tgt, it0, b, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
     }
     CS_HIP_CHECK(hipMemsetAsync(n_active.p, 0, sizeof(int), s));
     // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
@@ -1140,32 +1175,6 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                          res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
       const int ptiles = (b + PF_HYP - 1) / PF_HYP;
-      // deal the live problems to the 8 XCDs, longest first onto the least loaded XCD
-      int live = 0;
-      {
-        std::vector<int> order;
-        for (int p = 0; p < n_prob; ++p)
-          if (!hp[p].done && hp[p].est_k > it0) order.push_back(p);
-        live = (int)order.size();
-        std::sort(order.begin(), order.end(), [&](int a, int c) { return hp[a].m > hp[c].m; });
-        std::vector<std::vector<int>> lists(8);
-        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int p : order) {
-          int best = 0;
-          for (int x = 1; x < 8; ++x)
-            if (load[x] < load[best]) best = x;
-          lists[best].push_back(p);
-          load[best] += pf_padded(hp[p].m);
-        }
-        pslots = 0;
-        for (int x = 0; x < 8; ++x) pslots = std::max(pslots, (int)lists[x].size());
-        if (pslots < 1) pslots = 1;
-        h_xcd.assign((size_t)8 * pslots, -1);
-        for (int x = 0; x < 8; ++x)
-          for (size_t i = 0; i < lists[x].size(); ++i) h_xcd[(size_t)x * pslots + i] = lists[x][i];
-      }
-      CS_HIP_CHECK(hipMemcpyAsync(xcd_prob.p, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
-                                  hipMemcpyHostToDevice, s));
       // 768 workgroups are resident (3 per CU): split the pair range until there are >= 8 rounds of
       // workgroups, as long as a workgroup keeps >= 8 stages
       int psplits = (int)((8 * 768 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
