@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4, help="queries in the CPU baseline sample")
     ap.add_argument("--catalog", type=int, default=N_CATALOG)
+    ap.add_argument("--pipeline", type=int, default=2, help="query batches in flight (host threads x HIP streams)")
     return ap.parse_args()
 
 
@@ -132,16 +134,45 @@ def main():
 
     log("setup done: catalog %d clouds embedded in %.2fs, %d query batches resident" %
         (C, catalog_embed_s, len(q_dev)))
-    for b in range(args.warmup):
-        step(b)
+    # Query batches are independent: `--pipeline D` keeps D of them in flight, each driven by its own
+    # host thread on its own HIP stream, so the host work of one batch (index plumbing, the per-chunk
+    # RANSAC control loop) overlaps the kernels of another.  D = 1 is the plain sequential loop.
+    depth = max(1, min(args.pipeline, args.steps))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else []
+
+    def run_steps(first, last):
+        if depth == 1:
+            for b in range(first, last):
+                step(b)
+            return
+        errors = []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(dev_index)
+                with torch.cuda.stream(streams[w]):
+                    for b in range(first + w, last, depth):
+                        step(b)
+                    streams[w].synchronize()
+            except BaseException as e:  # surface worker failures in the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(depth)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    run_steps(0, args.warmup)
     log("warmup done")
     results.clear()
     _lib.prof_enable(True)
     _lib.prof_reset()
     barrier()
     t_start = time.time()
-    for b in range(args.warmup, args.warmup + args.steps):
-        step(b)
+    run_steps(args.warmup, args.warmup + args.steps)
     barrier()
     elapsed = time.time() - t_start
     _lib.prof_enable(False)
@@ -214,7 +245,7 @@ def main():
                                    "32 queries/step, 10k pts @ voxel 0.03, ResUNetBN2C+embedding random init, "
                                    "top-1 retrieval, sym_pose RANSAC 100000x10)" % C,
                        "queries_per_step": BATCH, "catalog": C, "catalog_embed_s": catalog_embed_s,
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "batches_in_flight": depth,
                        "ransac_problems_per_query": nprob / (args.steps * BATCH),
                        "ransac_mean_iters": float(iters_all.mean()),
                        "top1_hit_rate": hits / (args.steps * BATCH),

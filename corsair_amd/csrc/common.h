@@ -34,6 +34,7 @@ void set_error(const char* fmt, ...);
 // Size-class caching device allocator for library-owned scratch and map storage.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
+void pool_use_stream(hipStream_t s);  // see runtime.hip: scratch is cached per (thread, stream)
 
 template <typename T>
 struct PoolBuf {

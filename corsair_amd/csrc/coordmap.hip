@@ -375,6 +375,7 @@ int cs_coordmap_create(const int32_t* d_coords, int64_t n, int tensor_stride, vo
   CS_REQUIRE(n == 0 || d_coords, CS_ERR_INVALID, "cs_coordmap_create: coords is NULL");
   CS_REQUIRE(tensor_stride >= 1, CS_ERR_INVALID, "cs_coordmap_create: bad tensor stride");
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   ProfScope prof("kmap", s);
   cs_coordmap* m = new cs_coordmap();
   m->n = n;
@@ -431,6 +432,7 @@ int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coord
   *out = nullptr;
   CS_REQUIRE(stride >= 2, CS_ERR_INVALID, "cs_coordmap_stride: stride must be >= 2");
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   ProfScope prof("kmap", s);
   const int64_t n = in->n;
   const int cell = in->tensor_stride * stride;
@@ -546,6 +548,7 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     sign = -1;
   }
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   ProfScope prof("kmap", s);
   cs_kernelmap* km = new cs_kernelmap();
   km->n_out = out->n;
@@ -652,6 +655,7 @@ int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in,
              "cs_kernelmap_export: capacity %lld < %lld pairs", (long long)capacity,
              (long long)km->num_pairs);
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   const int64_t total = km->n_out * km->kvol;
   if (total == 0) return 0;
   CS_REQUIRE(total < (1LL << 31), CS_ERR_UNSUPPORTED, "cs_kernelmap_export: table too large");

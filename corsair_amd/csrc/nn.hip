@@ -821,6 +821,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
              CS_ERR_INVALID, "cs_knn_feat: labels and perm must be given together");
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   // 16-d features with k <= KNM_KK - 2 go through the f64 matrix pipe (shortlist + canonical rescore);
   // CS_KNN_MFMA=0 forces the all-VALU exact kernel
   const char* env = getenv("CS_KNN_MFMA");
@@ -903,8 +904,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
                          d_tf, cand.p, k, d_idx, d_dist);
       CS_LAUNCH_CHECK();
     }
-    CS_HIP_CHECK(hipStreamSynchronize(s));  // scratch returns to the pool
-    return CS_OK;
+    return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
   }
   {
     ProfScope prof("knn", s, knn_flop);
@@ -920,8 +920,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
                          d_tlabel, d_perm, d_idx, d_dist);
     CS_LAUNCH_CHECK();
   }
-  CS_HIP_CHECK(hipStreamSynchronize(s));  // dwork returns to the pool
-  return CS_OK;
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
@@ -932,6 +931,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   CS_REQUIRE(nx < (1LL << 31), CS_ERR_UNSUPPORTED, "cs_l2_topk: catalog too large");
   if (nq == 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   ProfScope prof("topk", s, 2.0 * (double)nq * (double)nx * (double)d);
   // large problems with a short list: shortlist on the f64 matrix pipe, exact re-score
   const char* force = getenv("CS_TOPK_MFMA");
@@ -957,8 +957,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
     hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
                        ci.p, nq * k, d_idx, d_dist);
     CS_LAUNCH_CHECK();
-    CS_HIP_CHECK(hipStreamSynchronize(s));
-    return CS_OK;
+    return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
   }
   // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
   int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);
@@ -980,8 +979,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
                      ci.p, nq * k, d_idx, d_dist);
   CS_LAUNCH_CHECK();
-  CS_HIP_CHECK(hipStreamSynchronize(s));
-  return CS_OK;
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
 static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float* d_tgt,
@@ -991,6 +989,7 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
              "cs_chamfer_1dir: NULL argument");
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   std::vector<ChamferWork> work;
   std::vector<int32_t> slot_begin(n_prob + 1, 0);
   std::vector<int64_t> src_count(n_prob, 0);
@@ -1035,8 +1034,7 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
                        partial.p, dslot.p, dcount.p, n_prob, reduce_max, d_out);
     CS_LAUNCH_CHECK();
   }
-  CS_HIP_CHECK(hipStreamSynchronize(s));
-  return CS_OK;
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
 int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,

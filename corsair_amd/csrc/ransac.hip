@@ -27,6 +27,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -992,16 +993,40 @@ __global__ void k_ransac_finish(const RansacProb* __restrict__ probs, int n_prob
 
 using namespace cs;
 
+// page-locked host staging buffer of the calling thread (grown on demand, freed at thread exit)
+namespace {
+struct PinnedScratch {
+  char* p = nullptr;
+  size_t n = 0;
+  ~PinnedScratch() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+thread_local PinnedScratch t_pinned;
+char* pinned_scratch(size_t bytes) {
+  if (t_pinned.n < bytes) {
+    if (t_pinned.p) (void)hipHostFree(t_pinned.p);
+    t_pinned.p = nullptr;
+    t_pinned.n = 0;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    t_pinned.p = static_cast<char*>(q);
+    t_pinned.n = bytes;
+  }
+  return t_pinned.p;
+}
+}  // namespace
+
 // prefilter diagnostics: {bound violations, hypotheses checked, sum of (bound - exact)} from
 // CS_RANSAC_CHECK runs, {survivors, hypotheses evaluated} always
-static unsigned long long g_pf_stats[5] = {0, 0, 0, 0, 0};
+static std::atomic<unsigned long long> g_pf_stats[5];  // zero-initialised (static storage)
 
 extern "C" {
 
 void cs_ransac_prefilter_stats(uint64_t out[5], int reset) {
   for (int i = 0; i < 5; ++i) {
-    if (out) out[i] = g_pf_stats[i];
-    if (reset) g_pf_stats[i] = 0;
+    if (out) out[i] = g_pf_stats[i].load();
+    if (reset) g_pf_stats[i].store(0);
   }
 }
 
@@ -1018,6 +1043,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
              "cs_ransac_batch: confidence must be in (0, 1]");
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   const int64_t total = h_off[n_prob] - h_off[0];
   CS_REQUIRE(h_off[0] == 0 && total >= 0, CS_ERR_INVALID, "cs_ransac_batch: bad offsets");
   CS_REQUIRE(total == 0 || (d_src && d_tgt), CS_ERR_INVALID, "cs_ransac_batch: NULL correspondences");
@@ -1050,13 +1076,22 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const bool use_pf = !(env_pf && env_pf[0] == '0') && total > 0;
   const bool check = use_pf && env_ck && env_ck[0] == '1';
   const int pf_from = 512;
-  PoolBuf<RansacProb> probs(n_prob);
+  // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
+  // [RansacProb x n_prob | n_surv int32 x n_prob (padded to 8 B) | n_active int32]
+  const size_t st_probs = sizeof(RansacProb) * (size_t)n_prob;
+  const size_t st_surv = ((sizeof(int32_t) * (size_t)n_prob + 7) / 8) * 8;
+  const size_t st_bytes = st_probs + st_surv + 8;
+  PoolBuf<char> state(st_bytes);
+  RansacProb* const d_probs = reinterpret_cast<RansacProb*>(state.p);
+  int32_t* const d_nsurv = reinterpret_cast<int32_t*>(state.p + st_probs);
+  int* const d_nactive = reinterpret_cast<int*>(state.p + st_probs + st_surv);
+  char* const h_state = pinned_scratch(st_bytes);
+  CS_REQUIRE(state.p && h_state, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   PoolBuf<float> pk((size_t)tot1 * 6);
   PoolBuf<float> hyp((size_t)n_prob * 12 * bmax);
   PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax), cand((size_t)n_prob * bmax);
   PoolBuf<unsigned long long> cand_err((size_t)n_prob * bmax);
-  PoolBuf<int> n_active(1);
-  CS_REQUIRE(probs.p && pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p && n_active.p,
+  CS_REQUIRE(pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   const bool pf_alloc = use_pf && max_iter > pf_from;
   // f16 pair image: every problem padded to whole LDS stages
@@ -1067,18 +1102,17 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   PoolBuf<int64_t> off16(n_prob + 1);
   PoolBuf<float> c_h(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
-  PoolBuf<int32_t> n_surv(n_prob);
   PoolBuf<unsigned> smax_bits(n_prob);
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
-  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && n_surv.p && smax_bits.p &&
+  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && smax_bits.p &&
                  exact_dbg.p && chk_stats.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   std::vector<int32_t> h_surv(n_prob), h_xcd;
   int pslots = 1;
   PoolBuf<int32_t> xcd_prob((size_t)8 * n_prob);
   CS_REQUIRE(xcd_prob.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
-  CS_HIP_CHECK(hipMemcpyAsync(probs.p, hp.data(), sizeof(RansacProb) * n_prob,
+  CS_HIP_CHECK(hipMemcpyAsync(d_probs, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
     hipLaunchKernelGGL(k_ransac_pack, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
@@ -1093,7 +1127,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
                                 hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                       probs.p, off16.p, d_src, d_tgt, B16.p, smax_bits.p);
+                       d_probs, off16.p, d_src, d_tgt, B16.p, smax_bits.p);
     CS_LAUNCH_CHECK();
   }
   // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
@@ -1102,7 +1136,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   (void)frexpf(thr2, &ex);
   const float scale = ldexpf(1.0f, 31 - ex);
   const double log_1mc = log(1.0 - confidence);  // -inf when confidence == 1: never exits early
-  unsigned long long st_surv = 0, st_eval = 0;
+  unsigned long long tot_surv = 0, tot_eval = 0;
   const int trace_it0 = getenv("CS_PF_TRACE") ? atoi(getenv("CS_PF_TRACE")) : -1;
   PoolBuf<unsigned long long> trace(trace_it0 >= 0 ? (size_t)8 * n_prob * 64 * 16 * 16 : 1);
   size_t trace_n = 0;
@@ -1149,10 +1183,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     {
       ProfScope prof("ransac_hyp", s);
       const int htiles = (b + 255) / 256;
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, probs.p,
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
                          d_src, d_tgt, it0, b, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
     }
-    CS_HIP_CHECK(hipMemsetAsync(n_active.p, 0, sizeof(int), s));
+    CS_HIP_CHECK(hipMemsetAsync(d_nsurv, 0, st_surv + 8, s));  // survivor counts and n_active
     // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
     // (transform 18 + squared distance 8 + compare/accumulate)
     double eval_pairs = 0.0;
@@ -1162,7 +1196,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (nh > b) nh = b;
       if (nh > 0) {
         eval_pairs += (double)nh * (double)hp[p].m;
-        st_eval += (unsigned long long)nh;
+        tot_eval += (unsigned long long)nh;
       }
     }
     if (!pf) {
@@ -1171,7 +1205,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                                       n_prob, s));
       ProfScope prof("ransac_eval", s, 30.0 * eval_pairs);
       hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                         dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                         dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
                          res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
       const int ptiles = (b + PF_HYP - 1) / PF_HYP;
@@ -1182,8 +1216,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (psplits > 16) psplits = 16;
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, s, probs.p, hyp.p, smax_bits.p, it0, b, bmax, thr2, A16.p, c_h.p);
-      CS_HIP_CHECK(hipMemsetAsync(n_surv.p, 0, sizeof(int32_t) * n_prob, s));
+                         0, s, d_probs, hyp.p, smax_bits.p, it0, b, bmax, thr2, A16.p, c_h.p);
       if (psplits > 1)
         CS_HIP_CHECK(hipMemset2DAsync(cnt_up.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                       n_prob, s));
@@ -1191,53 +1224,52 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         // 94 FLOP per (hypothesis, pair): the 47 multiply-adds of the hi/lo expansion
         ProfScope prof("ransac_pre", s, 94.0 * eval_pairs);
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
-        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, probs.p, off16.p, B16.p,
+        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, d_probs, off16.p, B16.p,
                            A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob.p, pslots, ptiles, cnt_up.p,
                            (trace_it0 == it0) ? trace.p : nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                         dim3(256), 0, s, probs.p, cnt_up.p, it0, b, bmax, res_cnt.p, hlist.p, n_surv.p);
+                         dim3(256), 0, s, d_probs, cnt_up.p, it0, b, bmax, res_cnt.p, hlist.p, d_nsurv);
       // exact counts of the survivors; few hypotheses, so the pair range is split finely
       int lsplits = 16;
       while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
       {
         ProfScope prof("ransac_eval", s);
         hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(tiles * lsplits), (unsigned)n_prob),
-                           dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
-                           res_cnt.p, hlist.p, n_surv.p);
+                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
+                           res_cnt.p, hlist.p, d_nsurv);
       }
       if (check) {
         CS_HIP_CHECK(hipMemset2DAsync(exact_dbg.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                       n_prob, s));
         hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                           dim3(256), 0, s, probs.p, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
                            exact_dbg.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
         hipLaunchKernelGGL(k_ransac_check_bound, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                           dim3(256), 0, s, probs.p, exact_dbg.p, cnt_up.p, it0, b, bmax, chk_stats.p);
+                           dim3(256), 0, s, d_probs, exact_dbg.p, cnt_up.p, it0, b, bmax, chk_stats.p);
       }
-      CS_HIP_CHECK(hipMemcpyAsync(h_surv.data(), n_surv.p, sizeof(int32_t) * n_prob,
-                                  hipMemcpyDeviceToHost, s));
     }
-    hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(64), 0, s, probs.p, n_prob,
-                       res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, n_active.p);
-    hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, probs.p, pk.p,
+    hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(64), 0, s, d_probs, n_prob,
+                       res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive);
+    hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
                        tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
     hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       probs.p, n_prob, hyp.p, cand.p, cand_err.p, it0, bmax);
+                       d_probs, n_prob, hyp.p, cand.p, cand_err.p, it0, bmax);
     CS_LAUNCH_CHECK();
-    int h_active = 0;
-    CS_HIP_CHECK(hipMemcpyAsync(&h_active, n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    // the per-problem state (est_k, done) comes back with the activity counter: it sizes the next
-    // chunk's work accounting and costs one small copy behind a synchronisation we need anyway
+    // the per-problem state (est_k, done), the survivor counts and the activity counter come back in
+    // one copy behind a synchronisation the chunk loop needs anyway
     std::vector<RansacProb> prev;
     if (pf) prev = hp;
-    CS_HIP_CHECK(hipMemcpyAsync(hp.data(), probs.p, sizeof(RansacProb) * n_prob,
-                                hipMemcpyDeviceToHost, s));
+    CS_HIP_CHECK(hipMemcpyAsync(h_state, state.p, st_bytes, hipMemcpyDeviceToHost, s));
     CS_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(hp.data(), h_state, st_probs);
+    memcpy(h_surv.data(), h_state + st_probs, sizeof(int32_t) * n_prob);
+    int h_active = 0;
+    memcpy(&h_active, h_state + st_probs + st_surv, sizeof(int));
     if (pf)
       for (int p = 0; p < n_prob; ++p)
-        if (!prev[p].done) st_surv += (unsigned long long)h_surv[p];
+        if (!prev[p].done) tot_surv += (unsigned long long)h_surv[p];
     it0 += b;
     if (h_active == 0) break;
   }
@@ -1250,8 +1282,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       fclose(f);
     }
   }
-  g_pf_stats[3] += st_surv;
-  g_pf_stats[4] += st_eval;
+  g_pf_stats[3] += tot_surv;
+  g_pf_stats[4] += tot_eval;
   if (check) {
     unsigned long long h_stats[4] = {0, 0, 0, 0};
     CS_HIP_CHECK(hipMemcpyAsync(h_stats, chk_stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, s));
@@ -1263,7 +1295,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                "cs_ransac_batch: prefilter bound violated for %llu hypotheses", h_stats[0]);
   }
   hipLaunchKernelGGL(k_ransac_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                     probs.p, n_prob, (double)scale, d_T, d_inliers, d_rmse, d_iters);
+                     d_probs, n_prob, (double)scale, d_T, d_inliers, d_rmse, d_iters);
   CS_LAUNCH_CHECK();
   CS_HIP_CHECK(hipStreamSynchronize(s));
   return CS_OK;

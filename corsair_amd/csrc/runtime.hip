@@ -20,9 +20,29 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- pool -------------------------------------------------------------------------------
+// Freed blocks are cached PER HOST THREAD: a thread drives one stream, so a block it frees while its
+// kernels are still queued is handed out again only to later work of the same stream (stream order
+// makes that safe without a synchronisation).  Another thread, on another stream, never receives it.
 static std::mutex g_pool_mu;
-static std::map<size_t, std::vector<void*>> g_free;   // size class -> blocks
-static std::map<void*, size_t> g_live;                // block -> size class
+static std::map<void*, size_t> g_live;                // block -> size class (all threads)
+struct ThreadCache {
+  std::map<size_t, std::vector<void*>> free_;          // size class -> blocks
+  ~ThreadCache() {
+    for (auto& kv : free_)
+      for (void* p : kv.second) (void)hipFree(p);      // fails harmlessly after runtime shutdown
+  }
+};
+static thread_local ThreadCache t_cache;
+static thread_local hipStream_t t_stream = nullptr;
+static thread_local bool t_stream_set = false;
+
+// Entry points that free scratch without waiting for their kernels call this first: the cache is only
+// stream-ordered, so a thread that switches streams drains the old one before blocks change hands.
+void pool_use_stream(hipStream_t s) {
+  if (t_stream_set && t_stream != s) (void)hipStreamSynchronize(t_stream);
+  t_stream = s;
+  t_stream_set = true;
+}
 
 static size_t size_class(size_t bytes) {
   size_t c = 256;
@@ -36,26 +56,29 @@ static size_t size_class(size_t bytes) {
   return c;
 }
 
+static void trim_thread_cache() {
+  for (auto& kv : t_cache.free_) {
+    for (void* p : kv.second) (void)hipFree(p);
+    kv.second.clear();
+  }
+}
+
 void* pool_alloc(size_t bytes) {
   size_t c = size_class(bytes);
-  {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_free.find(c);
-    if (it != g_free.end() && !it->second.empty()) {
-      void* p = it->second.back();
-      it->second.pop_back();
-      g_live[p] = c;
-      return p;
-    }
-  }
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, c);
-  if (e != hipSuccess) {
-    cs_pool_trim();
-    e = hipMalloc(&p, c);
+  auto it = t_cache.free_.find(c);
+  if (it != t_cache.free_.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+  } else {
+    hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {
-      set_error("hipMalloc(%zu) failed: %s", c, hipGetErrorString(e));
-      return nullptr;
+      trim_thread_cache();
+      e = hipMalloc(&p, c);
+      if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", c, hipGetErrorString(e));
+        return nullptr;
+      }
     }
   }
   std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -65,11 +88,15 @@ void* pool_alloc(size_t bytes) {
 
 void pool_free(void* p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  auto it = g_live.find(p);
-  if (it == g_live.end()) return;
-  g_free[it->second].push_back(p);
-  g_live.erase(it);
+  size_t c;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    c = it->second;
+    g_live.erase(it);
+  }
+  t_cache.free_[c].push_back(p);
 }
 
 // ---- profiling -----------------------------------------------------------------------------
@@ -77,6 +104,7 @@ static const char* kProfNames[] = {"conv",    "ransac_eval", "ransac_hyp", "knn"
                                    "topk",    "symcut",      "kmap",       "ransac_pre"};
 static constexpr int kNumProf = sizeof(kProfNames) / sizeof(kProfNames[0]);
 static int g_prof_on = 0;
+static std::mutex g_prof_mu;  // calls may come from several host threads (one stream each)
 struct ProfPending {
   hipEvent_t e0, e1;
 };
@@ -95,7 +123,10 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), st
   if (!g_prof_on) return;
   id = prof_id(name);
   if (id < 0) return;
-  g_prof_units[id] += units;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_units[id] += units;
+  }
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     id = -1;
     return;
@@ -106,11 +137,17 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), st
 ProfScope::~ProfScope() {
   if (id < 0) return;
   (void)hipEventRecord(e1, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_pending[id].push_back({e0, e1});
 }
 
 static void prof_drain(int id) {
-  for (auto& p : g_pending[id]) {
+  std::vector<ProfPending> pend;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    pend.swap(g_pending[id]);
+  }
+  for (auto& p : pend) {
     if (hipEventSynchronize(p.e1) == hipSuccess) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -121,7 +158,6 @@ static void prof_drain(int id) {
     (void)hipEventDestroy(p.e0);
     (void)hipEventDestroy(p.e1);
   }
-  g_pending[id].clear();
 }
 
 }  // namespace cs
@@ -138,13 +174,7 @@ int cs_device_count(void) {
   return n;
 }
 
-void cs_pool_trim(void) {
-  std::lock_guard<std::mutex> lk(cs::g_pool_mu);
-  for (auto& kv : cs::g_free) {
-    for (void* p : kv.second) (void)hipFree(p);
-    kv.second.clear();
-  }
-}
+void cs_pool_trim(void) { cs::trim_thread_cache(); }
 
 void cs_prof_enable(int on) { cs::g_prof_on = on; }
 

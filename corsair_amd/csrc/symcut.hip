@@ -422,6 +422,7 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
   CS_REQUIRE(n_anchor >= 1 && max_iter >= 1, CS_ERR_INVALID, "cs_symcut_fit: bad counts");
   if (n_cloud <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   std::vector<int64_t> off(h_off, h_off + n_cloud + 1), key_off(n_cloud + 1, 0);
   std::vector<int32_t> Ks(h_K, h_K + n_cloud);
   for (int c = 0; c < n_cloud; ++c) {
@@ -454,8 +455,7 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
                          d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error);
     CS_LAUNCH_CHECK();
   }
-  CS_HIP_CHECK(hipStreamSynchronize(s));
-  return CS_OK;
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
 int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, const int32_t* h_K,
@@ -464,6 +464,7 @@ int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, cons
              "cs_symcut_labels: NULL argument");
   if (n_cloud <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   PoolBuf<int64_t> d_off(n_cloud + 1);
   PoolBuf<int32_t> d_K(n_cloud);
   CS_REQUIRE(d_off.p && d_K.p, CS_ERR_HIP, "cs_symcut_labels: scratch allocation failed");
@@ -481,8 +482,7 @@ int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, cons
                        d_sel_centers, d_labels);
     CS_LAUNCH_CHECK();
   }
-  CS_HIP_CHECK(hipStreamSynchronize(s));
-  return CS_OK;
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
 }  // extern "C"

@@ -123,6 +123,7 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
   for (int s = 0; s <= n_seg; ++s) h_out_offsets[s] = 0;
   if (n == 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
   const float vs = (float)voxel_size;
   uint64_t cap = 1024;
   while (cap < (uint64_t)(2 * n)) cap <<= 1;

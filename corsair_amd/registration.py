@@ -74,6 +74,42 @@ def gate_and_order(centers, counts, min_cdist, max_err, n, K, force=False):
     return out
 
 
+def gate_and_order_batch(centers, counts, min_cdist, max_err, n, Ks, cand, force=False):
+    """gate_and_order for the pairs in `cand` at once (same arithmetic, NumPy over the pair axis).
+    centers [P,A,4,3], counts [P,A,4], min_cdist / max_err [P,A], n [P], Ks [P].
+    Returns (sel [P,4,3], ok [P])."""
+    P = centers.shape[0]
+    sel = np.zeros((P, 4, 3), np.float64)
+    ok = np.zeros(P, dtype=bool)
+    n = np.asarray(n, dtype=np.float64)
+    Ks = np.asarray(Ks)
+    cand = np.asarray(cand, dtype=np.int64)
+    for K in (2, 4):
+        idx = cand[Ks[cand] == K]
+        if idx.size == 0:
+            continue
+        ratios = counts[idx][:, :, :K].astype(np.float64) / n[idx][:, None, None]
+        std = np.sqrt(np.var(ratios, axis=2))
+        if force:
+            valid = np.isfinite(max_err[idx]) & (min_cdist[idx] > 0)
+        else:
+            valid = (min_cdist[idx] > 0.15) & (0.15 > max_err[idx]) & (std < 100)
+        has = valid.any(axis=1)
+        a = np.argmin(np.where(valid, std, np.inf), axis=1)
+        c = centers[idx, a]                                   # [G,4,3]
+        out = np.zeros((idx.size, 4, 3), np.float64)
+        if K == 2:
+            out[:, :2] = c[:, :2]
+        else:
+            d = np.linalg.norm(c[:, 0:1] - c[:, 1:4], axis=2)  # [G,3]
+            rank = np.argsort(d, axis=1, kind="stable")
+            order = np.stack([np.zeros(idx.size, np.int64), rank[:, 0] + 1, rank[:, 2] + 1, rank[:, 1] + 1], 1)
+            out = np.take_along_axis(c, order[:, :, None], axis=1)
+        sel[idx[has]] = out[has]
+        ok[idx[has]] = True
+    return sel, ok
+
+
 def part_configs(K, pos_sym):
     """Part assignments tried by sym_pose: K cyclic shifts, plus 4 shifts of the mirrored order
     [0,3,2,1] when pos_sym >= 2 (utils/symmetry.py:303-356)."""
@@ -130,12 +166,10 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
 
             c0, cnt0, mcd0, mer0 = fit(baseF, xyz0, off0, anc0)
             c1, cnt1, mcd1, mer1 = fit(posF, xyz1, off1, anc1)
-            for p in cand:
-                g0 = gate_and_order(c0[p], cnt0[p], mcd0[p], mer0[p], n0[p], Ks[p], force_gate)
-                g1 = gate_and_order(c1[p], cnt1[p], mcd1[p], mer1[p], n1[p], Ks[p], force_gate)
-                if g0 is not None and g1 is not None:
-                    sel0[p], sel1[p] = g0, g1
-                    ok[p] = True
+            g0, ok0 = gate_and_order_batch(c0, cnt0, mcd0, mer0, n0, Ks, cand, force_gate)
+            g1, ok1 = gate_and_order_batch(c1, cnt1, mcd1, mer1, n1, Ks, cand, force_gate)
+            ok = ok0 & ok1
+            sel0[ok], sel1[ok] = g0[ok], g1[ok]
         good = [p for p in range(P) if ok[p]]
         if good:
             lab0 = B.symcut_labels(xyz0, off0, Ks, torch.from_numpy(sel0).to(dev))
@@ -157,16 +191,34 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
             nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
                                 qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
-            row = 0
-            for j, p in enumerate(cfg_pair):
-                idx = nn_cfg[row:row + n0[p]]          # rows already in (part, original row) order
-                row += n0[p]
-                if bool((idx < 0).any()):
-                    continue  # a CAD part with fewer than k voxels: the reference cannot build it
-                prob_src.append(sorted_rows[off0[p]:off0[p + 1]].repeat_interleave(k))
-                prob_tgt.append((idx.to(torch.int64) + off1[p]).reshape(-1))
-                prob_len.append(n0[p] * k)
-                prob_pair.append(p)
+            # Assemble the correspondences of every configuration with a handful of device ops (no
+            # per-configuration launch or host round trip): configuration j owns the query rows
+            # sorted_rows[off0[p] : off0[p+1]] and the result rows nn_cfg[row_j : row_j + n0[p]].
+            lens = np.asarray([n0[p] for p in cfg_pair], dtype=np.int64)
+            row_start = np.concatenate([[0], np.cumsum(lens)])
+            # a CAD part with fewer than k voxels leaves -1 entries: the reference cannot build that
+            # configuration (one reduction + one small copy decides all of them)
+            neg = torch.cumsum((nn_cfg < 0).any(dim=1).to(torch.int32), 0)
+            neg = torch.cat([neg.new_zeros(1), neg])
+            ends = torch.from_numpy(row_start).to(dev)
+            bad = (neg[ends[1:]] - neg[ends[:-1]]).cpu().numpy() > 0
+            keep = [j for j in range(len(cfg_pair)) if not bad[j]]
+            if keep:
+                L = torch.from_numpy(lens[keep]).to(dev)
+                total = int(lens[keep].sum())
+                seg_first = torch.cumsum(L, 0) - L
+                base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(seg_first, L)
+                q_first = torch.tensor([off0[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
+                n_first = torch.from_numpy(row_start[:-1][keep]).to(dev)
+                t_first = torch.tensor([off1[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
+                q_rows = torch.repeat_interleave(q_first, L) + base
+                n_rows = torch.repeat_interleave(n_first, L) + base
+                prob_src.append(sorted_rows[q_rows].repeat_interleave(k))
+                prob_tgt.append((nn_cfg[n_rows].to(torch.int64)
+                                 + torch.repeat_interleave(t_first, L)[:, None]).reshape(-1))
+                for j in keep:
+                    prob_len.append(n0[cfg_pair[j]] * k)
+                    prob_pair.append(cfg_pair[j])
 
     # ---- 4. RANSAC over all hypotheses (registration_based_on_corr, utils/eval_pose.py:82-100) ----
     src_idx = torch.cat(prob_src)

@@ -12,7 +12,12 @@
  *   - plain C, no torch types; every pointer prefixed d_ is a DEVICE pointer owned by the caller
  *     (e.g. tensor.data_ptr()); h_ is a host pointer.  The library owns only the opaque map
  *     handles and an internal scratch pool.
- *   - every call takes the hipStream_t to launch on as a void* (0 = default stream).
+ *   - every call takes the hipStream_t to launch on as a void* (0 = default stream).  Work is
+ *     enqueued in stream order: device outputs (d_*) are valid once the stream reaches that point
+ *     (synchronise it before reading them on the host); host outputs (h_*, return values, sizes of
+ *     maps) are valid on return.  Scratch memory is cached per host thread and handed out again in
+ *     stream order, so a thread should keep to one stream (switching streams drains the old one);
+ *     different threads may drive different streams concurrently.
  *   - return value 0 = success, negative = error; cs_last_error() returns the (thread-local)
  *     message.  The Python host raises RuntimeError(cs_last_error()), mirroring ME's
  *     RuntimeError on coordinate-key mismatch.
@@ -231,7 +236,8 @@ int cs_prof_get(const char* name, double* total_ms, int64_t* launches);
 /* algorithmic work (FLOP) the bracketed launches of the family performed since the last reset */
 int cs_prof_get_units(const char* name, double* units);
 
-/* Return all cached scratch memory to the HIP runtime. */
+/* Return the calling thread's cached scratch memory to the HIP runtime.  Scratch is cached per host
+ * thread (one stream per thread), so the library may be driven from several threads at once. */
 void cs_pool_trim(void);
 
 #ifdef __cplusplus

@@ -347,6 +347,25 @@ def test_sym_pose_host_logic_part_configs():
         want = post.gate_and_order(centers, counts, mcd, mer, n, K)
         assert np.array_equal(got[:K], want)
     assert R.gate_and_order(centers, counts, mcd * 0, mer, 100, 4) is None
+    # the batched gate is the per-pair gate applied to every candidate pair (bit for bit)
+    P = 9
+    C = rng.uniform(-1, 1, (P, 30, 4, 3))
+    N = rng.integers(1, 100, (P, 30, 4)).astype(np.int32)
+    MCD = rng.uniform(0.05, 0.4, (P, 30))
+    MER = rng.uniform(0.05, 0.3, (P, 30))
+    MCD[4] = 0.0                                     # pair 4: no anchor passes
+    Ks = [2, 4, 4, 2, 4, 2, 4, 4, 2]
+    n = [int(N[p].sum(1).max()) for p in range(P)]
+    cand = [0, 1, 2, 4, 5, 6, 8]
+    for force in (False, True):
+        sel, ok = R.gate_and_order_batch(C, N, MCD, MER, n, Ks, cand, force)
+        for p in range(P):
+            one = R.gate_and_order(C[p], N[p], MCD[p], MER[p], n[p], Ks[p], force) if p in cand else None
+            assert ok[p] == (one is not None)
+            if one is not None:
+                assert np.array_equal(sel[p], one)
+            else:
+                assert not sel[p].any()
     assert R.draw_anchors(50, 100, 0) is None
     a = R.draw_anchors(500, 100, 3)
     assert len(np.unique(a)) == 100 and np.array_equal(a, R.draw_anchors(500, 100, 3))

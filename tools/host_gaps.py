@@ -34,4 +34,4 @@ for _ in range(3): step()
 torch.cuda.synchronize(); tot = time.perf_counter() - t0
 print("per step ms", tot/3*1e3, "inside backend calls", inside[0]/3*1e3, "python outside", (tot-inside[0])/3*1e3)
 pr = cProfile.Profile(); pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumtime').print_stats(22); print(s.getvalue()[:4500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(40); print(s.getvalue()[:9000])
