@@ -47,9 +47,13 @@ def test_l2_topk_bit_exact_vs_oracle(gpu, oracle_native, nq, nx, d, k):
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
 
 
-def test_knn_feat_bit_exact(gpu, oracle_native):
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_knn_feat_bit_exact(gpu, oracle_native, monkeypatch, mfma):
+    """Both code paths: the f64 matrix-pipe shortlist + canonical rescore (default for 16-d features) and
+    the all-VALU exact kernel (CS_KNN_MFMA=0) return the oracle's indices and distances."""
     from corsair_amd import backend as B
 
+    monkeypatch.setenv("CS_KNN_MFMA", mfma)
     rng = np.random.default_rng(0)
     sizes = [(700, 900), (1, 40), (513, 7), (0, 10), (300, 256)]
     qf = [_feat(rng, a) for a, _ in sizes]
@@ -66,8 +70,14 @@ def test_knn_feat_bit_exact(gpu, oracle_native):
         assert np.array_equal(idx[qoff[p]:qoff[p + 1]], wi), p
         assert np.array_equal(dist[qoff[p]:qoff[p + 1]], wd), p
     # labelled search, segments reused by several problems, problem-major output rows
-    lab_q = torch.from_numpy(rng.integers(0, 4, qoff[-1]).astype(np.int32)).to(gpu)
-    lab_t = torch.from_numpy(rng.integers(0, 4, toff[-1]).astype(np.int32)).to(gpu)
+    lab_q_h = rng.integers(0, 4, qoff[-1]).astype(np.int32)
+    lab_t_h = rng.integers(0, 4, toff[-1]).astype(np.int32)
+    lab_q_h[10:20] = -1          # queries without a part: no neighbours
+    lab_t_h[30:60] = 9           # targets without a part: never matched
+    lab_t_h[toff[4]:toff[5]] = 1
+    lab_t_h[toff[4]:toff[4] + 3] = 0   # segment 4: part 0 has 3 targets < k -> -1 padding
+    lab_q = torch.from_numpy(lab_q_h).to(gpu)
+    lab_t = torch.from_numpy(lab_t_h).to(gpu)
     perms = [[1, 2, 3, 0], [0, 3, 2, 1], [2, 2, 0, 0]]
     qseg, tseg = [0, 0, 4], [0, 0, 4]
     perm_t = torch.tensor([p + [-3] * 4 for p in perms], dtype=torch.int32, device=gpu)
