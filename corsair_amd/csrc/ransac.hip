@@ -255,18 +255,15 @@ constexpr int RC_TILES = RC_CHUNK / 32;   // 32-correspondence MFMA tiles per st
 
 // LIST: the hypotheses are the survivors of the prefilter, hlist[p][0 .. n_surv[p]) (any order).
 template <bool LIST>
-__global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
-                                                      const float* __restrict__ pk, int64_t total,
-                                                      const float* __restrict__ hyp, int it0,
-                                                      int bcount, int bmax, int splits, float thr2,
-                                                      int32_t* __restrict__ res_cnt,
-                                                      const int32_t* __restrict__ hlist,
-                                                      const int32_t* __restrict__ n_surv) {
-  // [buf][c][j]: c = 0..2 source xyz, c = 3..5 NEGATED target xyz (the MFMA accumulator input)
-  __shared__ __attribute__((aligned(16))) float lds[2][6][RC_CHUNK];
-  const int p = blockIdx.y;
-  const int tile = blockIdx.x / splits;
-  const int split = blockIdx.x - tile * splits;
+__device__ __forceinline__ void ransac_count_tile(float (*lds)[6][RC_CHUNK], const int p, const int tile,
+                                                  const int split,
+                                                  const RansacProb* __restrict__ probs,
+                                                  const float* __restrict__ pk, int64_t total,
+                                                  const float* __restrict__ hyp, int it0,
+                                                  int bcount, int bmax, int splits, float thr2,
+                                                  int32_t* __restrict__ res_cnt,
+                                                  const int32_t* __restrict__ hlist,
+                                                  const int32_t* __restrict__ n_surv) {
   const RansacProb pr = probs[p];
   if (pr.done) return;
   const int nlist = LIST ? n_surv[p] : 0;
@@ -393,6 +390,35 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
       res_cnt[(int64_t)p * bmax + hsel] = cnt;
     else
       atomicAdd(&res_cnt[(int64_t)p * bmax + hsel], cnt);
+  }
+}
+
+// grid: x = (hypothesis tile of 128) * splits + split, y = problem.  LIST: the survivor count is only
+// known on the device, so a fixed number of tile slots (gridDim.x / splits) strides over the list.
+template <bool LIST>
+__global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
+                                                      const float* __restrict__ pk, int64_t total,
+                                                      const float* __restrict__ hyp, int it0,
+                                                      int bcount, int bmax, int splits, float thr2,
+                                                      int32_t* __restrict__ res_cnt,
+                                                      const int32_t* __restrict__ hlist,
+                                                      const int32_t* __restrict__ n_surv) {
+  // [buf][c][j]: c = 0..2 source xyz, c = 3..5 NEGATED target xyz (the MFMA accumulator input)
+  __shared__ __attribute__((aligned(16))) float lds[2][6][RC_CHUNK];
+  const int p = blockIdx.y;
+  const int tile0 = blockIdx.x / splits;
+  const int split = blockIdx.x - tile0 * splits;
+  if (LIST) {
+    const int nlist = n_surv[p];
+    const int tstride = gridDim.x / splits;
+    for (int tile = tile0; tile * 128 < nlist; tile += tstride) {
+      ransac_count_tile<LIST>(lds, p, tile, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
+                              res_cnt, hlist, n_surv);
+      __syncthreads();  // the next tile restages LDS
+    }
+  } else {
+    ransac_count_tile<LIST>(lds, p, tile0, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
+                            res_cnt, hlist, n_surv);
   }
 }
 
@@ -818,17 +844,27 @@ __device__ __forceinline__ int est_bound(int c, int m, int ransac_n, double log_
 }
 
 // One wave per problem: sequential-semantics replay of the chunk from the inlier counts alone.
-__global__ __launch_bounds__(64) void k_ransac_scan1(RansacProb* probs, int n_prob,
+__global__ __launch_bounds__(256) void k_ransac_scan1(RansacProb* probs, int n_prob,
                                                      const int32_t* __restrict__ res_cnt, int it0,
                                                      int bcount, int bmax, int ransac_n,
                                                      int max_iter, double log_1mc,
                                                      int32_t* __restrict__ cand, int* n_active) {
+  // The chunk's counts are staged in LDS by all four waves (coalesced), then wave 0 replays them: lane l
+  // owns the contiguous segment [l seg, (l+1) seg).  Element h of lane l sits at h + l, which spreads
+  // the lanes' same-offset reads over the banks.
+  extern __shared__ int32_t lcnt[];
   const int p = blockIdx.x;
-  const int lane = threadIdx.x;
   RansacProb pr = probs[p];
   if (pr.done) return;
-  const int32_t* cnt = res_cnt + (int64_t)p * bmax;
   const int seg = (bcount + 63) / 64;
+  {
+    const int32_t* g = res_cnt + (int64_t)p * bmax;
+    for (int h = threadIdx.x; h < bcount; h += 256) lcnt[h + h / seg] = g[h];
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int32_t* cnt = lcnt + lane;  // cnt[h] for h in this lane's segment
   const int s0 = lane * seg, s1 = min(bcount, s0 + seg);
   // 1. exclusive prefix max of the counts over lanes, seeded with the carried best
   int lmax = 0;
@@ -1236,7 +1272,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
       {
         ProfScope prof("ransac_eval", s);
-        hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(tiles * lsplits), (unsigned)n_prob),
+        const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
+        hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(ltiles * lsplits), (unsigned)n_prob),
                            dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
                            res_cnt.p, hlist.p, d_nsurv);
       }
@@ -1250,7 +1287,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                            dim3(256), 0, s, d_probs, exact_dbg.p, cnt_up.p, it0, b, bmax, chk_stats.p);
       }
     }
-    hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(64), 0, s, d_probs, n_prob,
+    static const hipError_t scan1_lds = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(k_ransac_scan1), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    CS_REQUIRE(scan1_lds == hipSuccess, CS_ERR_HIP, "cs_ransac_batch: cannot reserve LDS for k_ransac_scan1");
+    hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(256), sizeof(int32_t) * (b + 64), s, d_probs, n_prob,
                        res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive);
     hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
                        tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
