@@ -321,7 +321,8 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   const bool mfma_ok = (cin % 32 == 0) && (cout % 4 == 0) && (ld_in % 4 == 0) &&
                        aligned16(d_in) && aligned16(d_w);
   if (mfma_ok) {
-    if (cout % 128 == 0) {
+    // 64 x 128 tiles unless that leaves half of the 256 CUs without a workgroup (coarsest level)
+    if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) > 128) {
       dim3 grid((unsigned)ceil_div(n_out, 64), (unsigned)(cout / 128));
       hipLaunchKernelGGL((k_conv_mfma<2, 2, 2>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
                          d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
