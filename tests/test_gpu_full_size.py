@@ -1,0 +1,161 @@
+"""BASELINE.json full sizes (config C2 shapes: 32-cloud batches of 10 000 points @ 0.03, Q = 993 x
+C = 652 x 256-d retrieval, ~22 k correspondences x 100 000 RANSAC iterations) checked through
+size-independent properties -- the oracle is only fast enough for the small cases of the other files:
+determinism, batch independence, self-retrieval / permutation equivariance / sortedness, pose round
+trips, recount of the reported inliers, invariance of the result to the prefilter."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_batch32_is_deterministic_and_sample_independent(gpu):
+    from corsair_amd import engine, synth
+    from tests.helpers import make_batch
+
+    ids = list(range(40, 72))
+    coords, feats, origins, off = make_batch(ids, n_points=10000, voxel=0.03)
+    assert 90_000 < coords.shape[0] < 220_000          # ~4.5 k voxels per cloud
+    sd, emb = synth.make_state_dicts(31)
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    C, F = torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu)
+    def run(c, f, n_batch):
+        out, feat8, maps = eng.forward(c, f)
+        return out, eng.embed(feat8, maps, n_batch)
+
+    out1, glob1 = run(C, F, 32)
+    out2, glob2 = run(C, F, 32)
+    assert torch.equal(out1, out2) and torch.equal(glob1, glob2)       # fixed summation order: bit-stable
+    assert out1.shape == (coords.shape[0], 16) and glob1.shape == (32, 256)
+    assert torch.allclose(out1.norm(dim=1), torch.ones_like(out1[:, 0]), atol=1e-5)
+    # a cloud's voxel features and descriptor do not depend on its batch mates (conv, BN-eval, per-sample max)
+    for j in (0, 13, 31):
+        c1, f1, _, _ = make_batch([ids[j]], n_points=10000, voxel=0.03)
+        o, g = run(torch.from_numpy(c1).to(gpu), torch.from_numpy(f1).to(gpu), 1)
+        assert torch.equal(o, out1[off[j]:off[j + 1]]), j
+        assert torch.equal(g[0], glob1[j]), j
+
+
+def test_retrieval_c2_properties(gpu):
+    from corsair_amd import backend as B, synth
+
+    Q, C, D, K = 993, 652, 256, 65                     # chair: pos_n = int(0.1 * 652) = 65
+    q = torch.from_numpy(synth.make_descriptors(Q, D, 1234)).to(gpu)
+    x = torch.from_numpy(synth.make_descriptors(C, D, 4321)).to(gpu)
+    idx, dist = B.l2_topk(q, x, K, return_distance=True)
+    idx_h, dist_h = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (np.diff(dist_h, axis=1) >= 0).all()                        # ascending
+    assert all(len(set(r)) == K for r in idx_h) and idx_h.min() >= 0 and idx_h.max() < C
+    # distances are the canonical f64 chain of the returned rows
+    xs, qs = x.cpu().numpy().astype(np.float64), q.cpu().numpy().astype(np.float64)
+    rows = [0, 17, 500, 992]
+    for r in rows:
+        d = np.sqrt(((qs[r][None, :] - xs[idx_h[r]]) ** 2).sum(1))
+        assert np.allclose(d, dist_h[r], rtol=1e-13, atol=0)
+        # nothing outside the list is closer than the last entry
+        rest = np.setdiff1d(np.arange(C), idx_h[r])
+        assert np.sqrt(((qs[r][None, :] - xs[rest]) ** 2).sum(1)).min() >= dist_h[r, -1]
+    # self retrieval: a catalog row queried against the catalog finds itself at distance 0
+    own, d_own = B.l2_topk(x, x, 1, return_distance=True)
+    assert torch.equal(own[:, 0].cpu(), torch.arange(C)) and float(d_own.max()) == 0.0
+    # permutation equivariance: permuting the catalog permutes the ids, distances unchanged
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(C)).to(gpu)
+    idx_p, dist_p = B.l2_topk(q, x[perm], K, return_distance=True)
+    assert torch.equal(dist_p, dist)
+    assert torch.equal(perm[idx_p], idx)               # no ties in random descriptors
+
+
+def _pairs(rng, m, inlier_frac, noise, pose_id):
+    from corsair_amd import synth
+
+    src = rng.uniform(-0.8, 0.8, (m, 3)).astype(np.float32)
+    T = synth.random_pose(pose_id, max_trans=0.5)
+    tgt = synth.apply_pose(src, T) + rng.normal(0, noise, (m, 3)).astype(np.float32)
+    bad = rng.random(m) > inlier_frac
+    tgt[bad] = rng.uniform(-1.2, 1.2, (int(bad.sum()), 3)).astype(np.float32)
+    return src, tgt.astype(np.float32), T
+
+
+def _recount(src, tgt, T, max_corr):
+    """Inlier count and rmse under T with the library's canonical f32 chain."""
+    f = np.float32
+    R, t = T[:3, :3].astype(f), T[:3, 3].astype(f)
+    d = np.empty((len(src), 3), f)
+    for c in range(3):
+        acc = (R[c, 0] * src[:, 0]).astype(np.float64) - tgt[:, c].astype(np.float64)   # fma(r0, sx, -q)
+        acc = acc.astype(f)
+        acc = (R[c, 1].astype(np.float64) * src[:, 1] + acc).astype(f)
+        acc = (R[c, 2].astype(np.float64) * src[:, 2] + acc).astype(f)
+        d[:, c] = (acc + t[c]).astype(f)
+    d2 = (d[:, 0].astype(np.float64) * d[:, 0]).astype(f)
+    d2 = (d[:, 1].astype(np.float64) * d[:, 1] + d2).astype(f)
+    d2 = (d[:, 2].astype(np.float64) * d[:, 2] + d2).astype(f)
+    inl = d2 < f(max_corr) * f(max_corr)
+    return int(inl.sum())
+
+
+def test_ransac_full_size_round_trip_and_prefilter_invariance(gpu, monkeypatch):
+    """22 700 pairs (5 x 4 540 voxels), 100 000 iterations: (a) a 45 %-inlier problem exits early and
+    recovers the pose, (b) a 4 %-inlier problem runs all iterations, (c) the reported inlier counts are
+    exactly the recount under the returned transform, (d) exact-only and prefiltered runs agree bit for
+    bit."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(2)
+    specs = [(22700, 0.45, 0), (22700, 0.04, 1), (11350, 0.10, 2)]
+    probs = [_pairs(rng, m, f, 0.01, i) for m, f, i in specs]
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+
+    def run():
+        return [t.cpu().numpy() for t in B.ransac_batch(S, D, off, 0.2, 10, 100000, 0.999, 3)]
+
+    monkeypatch.setenv("CS_RANSAC_PREFILTER", "0")
+    exact = run()
+    monkeypatch.setenv("CS_RANSAC_PREFILTER", "1")
+    pre = run()
+    for a, b in zip(exact, pre):
+        assert np.array_equal(a, b)
+    T, inl, rmse, iters = pre
+    assert iters[0] < 100000 and iters[1] == 100000
+    # no refinement step, as in Open3D: the estimate is the best 10-point fit under max_corr = 0.2
+    assert np.abs(T[0][:3, :3] - probs[0][2][:3, :3]).max() < 0.15
+    assert np.abs(T[0][:3, 3] - probs[0][2][:3, 3]).max() < 0.15
+    assert inl[0] > 0.4 * 22700
+    for p, (src, tgt, _) in enumerate(probs):
+        assert _recount(src, tgt, T[p], 0.2) == inl[p], p
+
+
+def test_knn_and_chamfer_full_size_properties(gpu):
+    from corsair_amd import backend as B, synth
+
+    rng = np.random.default_rng(4)
+    n0, n1 = 8000, 8200
+    qf = rng.normal(size=(n0, 16)).astype(np.float32)
+    tf = rng.normal(size=(n1, 16)).astype(np.float32)
+    qf /= np.linalg.norm(qf, axis=1, keepdims=True)
+    tf /= np.linalg.norm(tf, axis=1, keepdims=True)
+    idx, dist = B.knn_feat(torch.from_numpy(qf).to(gpu), [0, n0], torch.from_numpy(tf).to(gpu), [0, n1], 5,
+                           return_distance=True)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (np.diff(dist, axis=1) >= 0).all() and idx.min() >= 0 and idx.max() < n1
+    for r in rng.integers(0, n0, 40):
+        d = np.sqrt(((qf[r].astype(np.float64)[None, :] - tf.astype(np.float64)) ** 2).sum(1))
+        order = np.argsort(d, kind="stable")[:5]
+        assert np.array_equal(order, idx[r]), r
+        assert np.allclose(d[order], dist[r], rtol=1e-12)
+    # Chamfer: a cloud against its own rigid image, undone by the transform, is exactly 0; against
+    # itself with a translation of 0.25 along x it is at most 0.25 and positive
+    pc = synth.make_cloud(7, 15000)[:8000].astype(np.float32)
+    Tm = synth.random_pose(5, max_trans=0.3).astype(np.float32)
+    moved = synth.apply_pose(pc, Tm).astype(np.float32)
+    X = torch.from_numpy(pc).to(gpu)
+    Y = torch.from_numpy(moved).to(gpu)
+    shift = np.eye(4, dtype=np.float32)
+    shift[0, 3] = 0.25
+    cd = B.chamfer_1dir(torch.cat([X, X]), [0, 8000, 16000], torch.cat([Y, X]), [0, 8000, 16000],
+                        [0, 1], [0, 1], torch.from_numpy(np.stack([Tm, shift])).to(gpu)).cpu().numpy()
+    assert cd[0] < 1e-6                                # f32 transform of the same points
+    assert 0.0 < cd[1] <= 0.25 + 1e-6
