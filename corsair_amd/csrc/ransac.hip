@@ -1179,6 +1179,20 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   size_t trace_n = 0;
   if (trace_it0 >= 0) CS_HIP_CHECK(hipMemsetAsync(trace.p, 0, sizeof(unsigned long long) * (size_t)8 * n_prob * 64 * 16 * 16, s));
 
+  struct Event {
+    hipEvent_t e = nullptr;
+    ~Event() {
+      if (e) (void)hipEventDestroy(e);
+    }
+  } round_done;
+  CS_HIP_CHECK(hipEventCreateWithFlags(&round_done.e, hipEventDisableTiming));
+  bool hyp_ready = false;  // the hypotheses of the chunk at it0 are already enqueued
+  auto launch_hyp = [&](int first, int count) {
+    ProfScope prof("ransac_hyp", s);
+    const int htiles = (count + 255) / 256;
+    hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
+                       d_src, d_tgt, first, count, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
+  };
   int it0 = 0;
   while (it0 < max_iter) {
     int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
@@ -1217,12 +1231,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     }
     CS_HIP_CHECK(hipMemcpyAsync(xcd_prob.p, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
                                 hipMemcpyHostToDevice, s));
-    {
-      ProfScope prof("ransac_hyp", s);
-      const int htiles = (b + 255) / 256;
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
-                         d_src, d_tgt, it0, b, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
-    }
+    if (!hyp_ready) launch_hyp(it0, b);
+    hyp_ready = false;
     CS_HIP_CHECK(hipMemsetAsync(d_nsurv, 0, st_surv + 8, s));  // survivor counts and n_active
     // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
     // (transform 18 + squared distance 8 + compare/accumulate)
@@ -1303,7 +1313,18 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     std::vector<RansacProb> prev;
     if (pf) prev = hp;
     CS_HIP_CHECK(hipMemcpyAsync(h_state, state.p, st_bytes, hipMemcpyDeviceToHost, s));
-    CS_HIP_CHECK(hipStreamSynchronize(s));
+    CS_HIP_CHECK(hipEventRecord(round_done.e, s));
+    // The next chunk's hypotheses do not depend on this round's outcome (finished problems skip
+    // themselves on the device), so they are generated while the host waits for the state and sizes the
+    // next round: the host turnaround disappears from the GPU timeline.
+    if (it0 + b < max_iter) {
+      const int it1 = it0 + b;
+      int b1 = it1 < 256 ? 256 : (it1 < bmax ? it1 : bmax);
+      if (b1 > max_iter - it1) b1 = max_iter - it1;
+      launch_hyp(it1, b1);
+      hyp_ready = true;
+    }
+    CS_HIP_CHECK(hipEventSynchronize(round_done.e));
     memcpy(hp.data(), h_state, st_probs);
     memcpy(h_surv.data(), h_state + st_probs, sizeof(int32_t) * n_prob);
     int h_active = 0;
