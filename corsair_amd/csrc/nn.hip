@@ -775,6 +775,86 @@ __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__
   if (tid == 0) partial[wk.slot] = red[0];
 }
 
+// The same search on the f64 matrix pipe: A = [tx, ty, tz, |t|^2] (targets, LDS), B = [-2px, -2py, -2pz, 1]
+// (transformed sources, registers): one v_mfma_f64_16x16x4_f64 gives |t|^2 - 2 p.t for 16 x 16 pairs,
+// the ranking value of each source.  Every lane keeps the arg-min of its quarter of the targets, the
+// four candidates of a source are re-evaluated with the canonical chain and the smallest is the
+// result -- equal to the exhaustive chain unless two targets are within the expansion's rounding
+// (~5e-16 absolute in d^2) of the minimum, where the two values differ by less than that.
+constexpr int CHM_ST = 64;    // sources per workgroup (16 per wave)
+constexpr int CHM_TT = 512;   // targets per LDS stage
+__global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restrict__ work,
+                                                      const float* __restrict__ src,
+                                                      const float* __restrict__ tgt,
+                                                      const float* __restrict__ T, int reduce_max,
+                                                      double* __restrict__ partial) {
+  __shared__ double t4[CHM_TT * 4];
+  __shared__ double red[CHM_ST];
+  const ChamferWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 15;  // source within the wave (B side); target row within a 16-row tile (A side)
+  const int kq = lane >> 4;   // k slot of the operands; row group of the results
+  const int sloc = wave * 16 + col;
+  const bool active = sloc < wk.sn;
+  const float* Tp = T + (int64_t)wk.prob * 16;
+  double px = 0, py = 0, pz = 0;
+  {
+    const float* sp = src + (wk.s0 + (active ? sloc : 0)) * 3;
+    const double x = sp[0], y = sp[1], z = sp[2];
+    px = fma((double)Tp[0], x, fma((double)Tp[1], y, fma((double)Tp[2], z, (double)Tp[3])));
+    py = fma((double)Tp[4], x, fma((double)Tp[5], y, fma((double)Tp[6], z, (double)Tp[7])));
+    pz = fma((double)Tp[8], x, fma((double)Tp[9], y, fma((double)Tp[10], z, (double)Tp[11])));
+  }
+  const double b = kq == 0 ? -2.0 * px : (kq == 1 ? -2.0 * py : (kq == 2 ? -2.0 * pz : 1.0));
+  double best = INFINITY;
+  int bidx = -1;
+  for (int tbase = 0; tbase < wk.tn; tbase += CHM_TT) {
+    const int tcount = min(CHM_TT, wk.tn - tbase);
+    __syncthreads();
+    for (int j = tid; j < CHM_TT; j += 256) {
+      double x = 0.0, y = 0.0, z = 0.0, n2 = INFINITY;  // rows past the segment never win
+      if (j < tcount) {
+        const float* tp = tgt + (wk.t0 + tbase + j) * 3;
+        x = tp[0]; y = tp[1]; z = tp[2];
+        n2 = fma(z, z, fma(y, y, x * x));
+      }
+      t4[4 * j + 0] = x; t4[4 * j + 1] = y; t4[4 * j + 2] = z; t4[4 * j + 3] = n2;
+    }
+    __syncthreads();
+    for (int t = 0; t < (tcount + 15) / 16; ++t) {
+      const double a = t4[(16 * t + col) * 4 + kq];
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      // acc[r] = |t|^2 - 2 p.t of target row 16 t + kq + 4 r and source col
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (acc[r] < best) {
+          best = acc[r];
+          bidx = tbase + 16 * t + kq + 4 * r;
+        }
+      }
+    }
+  }
+  // canonical distance of this lane's candidate, then the smallest of the source's four lanes
+  double d = INFINITY;
+  if (bidx >= 0) {
+    const float* tp = tgt + (wk.t0 + bidx) * 3;
+    const double dx = px - (double)tp[0], dy = py - (double)tp[1], dz = pz - (double)tp[2];
+    d = fma(dz, dz, fma(dy, dy, dx * dx));
+  }
+  d = fmin(d, __shfl_xor(d, 16));
+  d = fmin(d, __shfl_xor(d, 32));
+  if (kq == 0) red[sloc] = active ? sqrt(d) : 0.0;
+  __syncthreads();
+  for (int off = CHM_ST / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] = reduce_max ? fmax(red[tid], red[tid + off]) : red[tid] + red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) partial[wk.slot] = red[0];
+}
+
 __global__ void k_chamfer_finish(const double* __restrict__ partial,
                                  const int32_t* __restrict__ slot_begin,
                                  const int64_t* __restrict__ src_count, int n_prob, int reduce_max,
@@ -990,6 +1070,10 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
+  // CS_CHAMFER_MFMA=0 selects the exhaustive all-VALU chain kernel
+  const char* env = getenv("CS_CHAMFER_MFMA");
+  const bool mfma = !(env && env[0] == '0');
+  const int64_t stile = mfma ? CHM_ST : 256;
   std::vector<ChamferWork> work;
   std::vector<int32_t> slot_begin(n_prob + 1, 0);
   std::vector<int64_t> src_count(n_prob, 0);
@@ -1001,11 +1085,11 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
                "cs_chamfer_1dir: bad segment in problem %d", p);
     slot_begin[p] = (int32_t)work.size();
     src_count[p] = sn;
-    for (int64_t q = 0; q < sn; q += 256) {
+    for (int64_t q = 0; q < sn; q += stile) {
       ChamferWork w;
       w.s0 = h_soff[ss] + q;
       w.t0 = h_toff[ts];
-      w.sn = (int32_t)(sn - q < 256 ? sn - q : 256);
+      w.sn = (int32_t)(sn - q < stile ? sn - q : stile);
       w.tn = (int32_t)tn;
       w.prob = p;
       w.slot = (int32_t)work.size();
@@ -1027,9 +1111,14 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
   for (const ChamferWork& w : work) ch_flop += 8.0 * (double)w.sn * (double)w.tn;
   {
     ProfScope prof("chamfer", s, ch_flop);
-    if (!work.empty())
-      hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
-                         d_tgt, d_T, reduce_max, partial.p);
+    if (!work.empty()) {
+      if (mfma)
+        hipLaunchKernelGGL(k_chamfer_mfma, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
+                           d_tgt, d_T, reduce_max, partial.p);
+      else
+        hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
+                           d_tgt, d_T, reduce_max, partial.p);
+    }
     hipLaunchKernelGGL(k_chamfer_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
                        partial.p, dslot.p, dcount.p, n_prob, reduce_max, d_out);
     CS_LAUNCH_CHECK();

@@ -92,8 +92,12 @@ def test_knn_feat_bit_exact(gpu, oracle_native, monkeypatch, mfma):
         row += a
 
 
-def test_chamfer_matches_oracle(gpu, oracle_native):
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_chamfer_matches_oracle(gpu, oracle_native, monkeypatch, mfma):
+    """f64 matrix-pipe arg-min + canonical re-evaluation (default) and the exhaustive VALU chain."""
     from corsair_amd import backend as B, synth
+
+    monkeypatch.setenv("CS_CHAMFER_MFMA", mfma)
 
     rng = np.random.default_rng(3)
     clouds = [rng.uniform(-1, 1, (n, 3)).astype(np.float32) for n in (1500, 777, 1, 300)]
