@@ -831,6 +831,48 @@ __global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const
   atomicAdd(&stats[2], (unsigned long long)(u - e > 0 ? u - e : 0));
 }
 
+// Exact counts when only a handful of hypotheses survive the prefilter (the normal case: ~2 per
+// problem and round): one workgroup per survivor walks the pairs with the canonical f32 chain.  The
+// MFMA list kernel above needs a 128-hypothesis tile per workgroup and costs ~110 us per round even for
+// two survivors; this one ~15 us.  grid: x = survivor slots (strided), y = problem.
+__global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __restrict__ probs,
+                                                          const float* __restrict__ pk, int64_t total,
+                                                          const float* __restrict__ hyp, int bmax,
+                                                          float thr2, int32_t* __restrict__ res_cnt,
+                                                          const int32_t* __restrict__ hlist,
+                                                          const int32_t* __restrict__ n_surv) {
+  __shared__ int red[4];
+  const int p = blockIdx.y;
+  const RansacProb pr = probs[p];
+  if (pr.done) return;
+  const int nlist = n_surv[p];
+  const int tid = threadIdx.x;
+  for (int c = blockIdx.x; c < nlist; c += gridDim.x) {
+    const int h = hlist[(int64_t)p * bmax + c];
+    const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
+    float R[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
+    int cnt = 0;
+    for (int i = tid; i < pr.m; i += 256) {
+      const int64_t g = pr.off + i;
+      const float sx = pk[0 * total + g], sy = pk[1 * total + g], sz = pk[2 * total + g];
+      // same chain as the MFMA pair: fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q))))
+      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -pk[3 * total + g]))) + R[3];
+      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -pk[4 * total + g]))) + R[7];
+      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -pk[5 * total + g]))) + R[11];
+      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+      cnt += d2 < thr2 ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) res_cnt[(int64_t)p * bmax + h] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
 // est_k implied by a best inlier count c (Open3D: log(1 - confidence) / log(1 - ratio^n))
 __device__ __forceinline__ int est_bound(int c, int m, int ransac_n, double log_1mc, int est_k0) {
   const double ratio = fmin(1.0, (double)c / (double)m);
@@ -1187,6 +1229,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   } round_done;
   CS_HIP_CHECK(hipEventCreateWithFlags(&round_done.e, hipEventDisableTiming));
   bool hyp_ready = false;  // the hypotheses of the chunk at it0 are already enqueued
+  int max_surv_prev = 1 << 30;  // survivors per problem in the previous prefiltered round (unknown: many)
   auto launch_hyp = [&](int first, int count) {
     ProfScope prof("ransac_hyp", s);
     const int htiles = (count + 255) / 256;
@@ -1283,10 +1326,16 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
       {
         ProfScope prof("ransac_eval", s);
-        const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
-        hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(ltiles * lsplits), (unsigned)n_prob),
-                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
-                           res_cnt.p, hlist.p, d_nsurv);
+        // the previous round's survivor counts pick the kernel (both are exact for any count)
+        if (max_surv_prev <= 32) {
+          hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
+                             tot1, hyp.p, bmax, thr2, res_cnt.p, hlist.p, d_nsurv);
+        } else {
+          const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
+          hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(ltiles * lsplits), (unsigned)n_prob),
+                             dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
+                             res_cnt.p, hlist.p, d_nsurv);
+        }
       }
       if (check) {
         CS_HIP_CHECK(hipMemset2DAsync(exact_dbg.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
@@ -1329,9 +1378,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     memcpy(h_surv.data(), h_state + st_probs, sizeof(int32_t) * n_prob);
     int h_active = 0;
     memcpy(&h_active, h_state + st_probs + st_surv, sizeof(int));
-    if (pf)
+    if (pf) {
+      max_surv_prev = 0;
       for (int p = 0; p < n_prob; ++p)
-        if (!prev[p].done) tot_surv += (unsigned long long)h_surv[p];
+        if (!prev[p].done) {
+          tot_surv += (unsigned long long)h_surv[p];
+          if (h_surv[p] > max_surv_prev) max_surv_prev = h_surv[p];
+        }
+    }
     it0 += b;
     if (h_active == 0) break;
   }
