@@ -838,10 +838,13 @@ __global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const
 __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __restrict__ probs,
                                                           const float* __restrict__ pk, int64_t total,
                                                           const float* __restrict__ hyp, int bmax,
-                                                          float thr2, int32_t* __restrict__ res_cnt,
+                                                          float thr2, float scale,
+                                                          int32_t* __restrict__ res_cnt,
+                                                          unsigned long long* __restrict__ err_by_h,
                                                           const int32_t* __restrict__ hlist,
                                                           const int32_t* __restrict__ n_surv) {
   __shared__ int red[4];
+  __shared__ unsigned long long rede[4];
   const int p = blockIdx.y;
   const RansacProb pr = probs[p];
   if (pr.done) return;
@@ -854,6 +857,7 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
 #pragma unroll
     for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
     int cnt = 0;
+    unsigned long long err = 0;  // fixed-point squared error of the inliers (exact integer sum, as k_ransac_err)
     for (int i = tid; i < pr.m; i += 256) {
       const int64_t g = pr.off + i;
       const float sx = pk[0 * total + g], sy = pk[1 * total + g], sz = pk[2 * total + g];
@@ -862,13 +866,25 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
       const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -pk[4 * total + g]))) + R[7];
       const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -pk[5 * total + g]))) + R[11];
       const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-      cnt += d2 < thr2 ? 1 : 0;
+      if (d2 < thr2) {
+        ++cnt;
+        err += (unsigned long long)(uint32_t)(d2 * scale);
+      }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    for (int off = 32; off >= 1; off >>= 1) {
+      cnt += __shfl_xor(cnt, off);
+      err += __shfl_xor(err, off);
+    }
+    if ((tid & 63) == 0) {
+      red[tid >> 6] = cnt;
+      rede[tid >> 6] = err;
+    }
     __syncthreads();
-    if (tid == 0) res_cnt[(int64_t)p * bmax + h] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+      res_cnt[(int64_t)p * bmax + h] = red[0] + red[1] + red[2] + red[3];
+      err_by_h[(int64_t)p * bmax + h] = rede[0] + rede[1] + rede[2] + rede[3];
+    }
     __syncthreads();
   }
 }
@@ -1020,9 +1036,12 @@ __global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict
   }
 }
 
+// cand_err is indexed by candidate slot (k_ransac_err) or, when by_h is set, by hypothesis
+// (k_ransac_count_few computed the error of every survivor along with its count)
 __global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const float* __restrict__ hyp,
                                const int32_t* __restrict__ cand,
-                               const unsigned long long* __restrict__ cand_err, int it0, int bmax) {
+                               const unsigned long long* __restrict__ cand_err, int by_h, int it0,
+                               int bmax) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_prob) return;
   RansacProb pr = probs[p];
@@ -1030,7 +1049,7 @@ __global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const float* __res
   bool changed = false;
   int best_h = -1;
   for (int c = 0; c < pr.n_cand; ++c) {
-    const unsigned long long e = cand_err[(int64_t)p * bmax + c];
+    const unsigned long long e = cand_err[(int64_t)p * bmax + (by_h ? cand[(int64_t)p * bmax + c] : c)];
     if (pr.chunk_max > pr.best_cnt || e < pr.best_err) {
       pr.best_cnt = pr.chunk_max;
       pr.best_err = e;
@@ -1241,6 +1260,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
     if (b > max_iter - it0) b = max_iter - it0;
     const bool pf = pf_alloc && it0 >= pf_from;
+    bool err_known = false;  // the fixed-point errors of all candidates are already in cand_err (by hypothesis)
     const int tiles = (b + 127) / 128;
     // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
     // chunk is small (integer partial sums combine exactly)
@@ -1329,7 +1349,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         // the previous round's survivor counts pick the kernel (both are exact for any count)
         if (max_surv_prev <= 32) {
           hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
-                             tot1, hyp.p, bmax, thr2, res_cnt.p, hlist.p, d_nsurv);
+                             tot1, hyp.p, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
+          err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
           hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(ltiles * lsplits), (unsigned)n_prob),
@@ -1352,10 +1373,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     CS_REQUIRE(scan1_lds == hipSuccess, CS_ERR_HIP, "cs_ransac_batch: cannot reserve LDS for k_ransac_scan1");
     hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(256), sizeof(int32_t) * (b + 64), s, d_probs, n_prob,
                        res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive);
-    hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
-                       tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
+    if (!err_known)
+      hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
+                         tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
     hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       d_probs, n_prob, hyp.p, cand.p, cand_err.p, it0, bmax);
+                       d_probs, n_prob, hyp.p, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax);
     CS_LAUNCH_CHECK();
     // the per-problem state (est_k, done), the survivor counts and the activity counter come back in
     // one copy behind a synchronisation the chunk loop needs anyway
