@@ -1,6 +1,7 @@
 // Symmetry part cut on gfx950: replaces symmetric_cut4 (utils/symmetry.py:182-259 of the reference).
 //
-// Per (cloud, anchor) workgroup:
+// Per (cloud, anchor) -- k_symcut_select (steps 1-2, one workgroup), k_symcut_kmeans (step 3, one thread
+// per restart), k_symcut_finish (step 4, one workgroup):
 //   1. f64 squared feature distance of every voxel to the anchor (fma chain over the 16 channels)
 //   2. exact selection of the n_nn (= 50) nearest voxels by an 8-pass MSB radix select on the
 //      distance bit patterns (ties -> smaller row), emitted in ascending row order -- this is the
@@ -13,6 +14,7 @@
 //      and the label histogram of the WHOLE cloud under the fitted centres.
 // The gate itself (dist.min() > 0.15 > max(error), smallest std of label fractions) and the
 // cyclic ordering of the 4 centres are a few flops per anchor and stay on the host.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -59,23 +61,43 @@ __device__ __forceinline__ int nearest_center(const KmState& st, int K, double p
   return best;
 }
 
+// Exclusive prefix sum of one int per thread over a 256-thread workgroup (wave shuffles + 4 partials).
+// All threads must call it; *total receives the sum.  wsum: 4 ints of LDS.
+__device__ __forceinline__ int block_excl_scan256(int v, int* wsum, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();  // wsum may still be read by a previous call
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) base += w < wave ? wsum[w] : 0;
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
+// (keeping the distance keys in LDS instead of the global scratch was measured: no gain, the keys stay
+// in L2)
 template <int DIM>
-__global__ __launch_bounds__(256) void k_symcut_fit(
+__global__ __launch_bounds__(256) void k_symcut_select(
     const float* __restrict__ feat, const float* __restrict__ xyz,
     const int64_t* __restrict__ off, const int32_t* __restrict__ anchors, int n_anchor,
     const int32_t* __restrict__ Ks, int n_nn, int n_init, int max_iter, uint64_t seed,
     unsigned long long* __restrict__ key_scratch, const int64_t* __restrict__ key_off,
     double* __restrict__ out_centers, int32_t* __restrict__ out_counts,
-    double* __restrict__ out_min_cdist, double* __restrict__ out_max_err) {
+    double* __restrict__ out_min_cdist, double* __restrict__ out_max_err,
+    double* __restrict__ pts_g, int32_t* __restrict__ nsel_g) {
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining;
   __shared__ int scan_a[256], scan_b[256];
-  __shared__ double pts[SYM_MAX_NN][3];
-  __shared__ double km_centers[SYM_MAX_INIT][12];
-  __shared__ double km_inertia[SYM_MAX_INIT];
-  __shared__ double sel_centers[12];
-  __shared__ int counts[4];
+  __shared__ int wsum[4];
+  double (*pts)[3] = reinterpret_cast<double (*)[3]>(pts_g + (int64_t)blockIdx.x * SYM_MAX_NN * 3);
 
   const int blk = blockIdx.x;
   const int cloud = blk / n_anchor;
@@ -91,6 +113,7 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
     if (tid == 0) {
       out_min_cdist[blk] = 0.0;
       out_max_err[blk] = INFINITY;
+      nsel_g[blk] = 0;  // the later stages skip this (cloud, anchor)
     }
     return;
   }
@@ -123,23 +146,40 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
     hist[tid] = 0;
     __syncthreads();
     const unsigned long long prefix = s_prefix;
+    // squared distances of unit-norm features share their leading bytes: in the first passes nearly
+    // every key lands in one or two bins, so equal consecutive digits are counted in a register and
+    // flushed with one LDS atomic per run instead of one per key
+    int last = -1, run = 0;
     for (int i = tid; i < n; i += 256) {
       const unsigned long long key = keys[i];
-      if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ULL)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int cum = 0, digit = 255;
-      const int rem = s_remaining;
-      for (int d = 0; d < 256; ++d) {
-        if (cum + hist[d] >= rem) {
-          digit = d;
-          break;
+      if (pass == 0 || (key >> (shift + 8)) == prefix) {
+        const int digit = (int)((key >> shift) & 255ULL);
+        if (digit == last) {
+          ++run;
+        } else {
+          if (run) atomicAdd(&hist[last], run);
+          last = digit;
+          run = 1;
         }
-        cum += hist[d];
       }
-      s_remaining = rem - cum;
-      s_prefix = (prefix << 8) | (unsigned long long)digit;
+    }
+    if (run) atomicAdd(&hist[last], run);
+    __syncthreads();
+    {
+      // digit = first bin whose inclusive count reaches the remaining rank (parallel scan of the 256 bins)
+      const int rem = s_remaining;
+      int total;
+      const int hv = hist[tid];
+      const int excl = block_excl_scan256(hv, wsum, &total);
+      const bool here = excl < rem && excl + hv >= rem;  // exactly one bin (or none: all in bin 255)
+      if (here) {
+        s_remaining = rem - excl;
+        s_prefix = (prefix << 8) | (unsigned long long)tid;
+      }
+      if (tid == 0 && total < rem) {  // cannot happen (rem <= selected keys); mirror the serial fallback
+        s_remaining = rem - (total - hist[255]);
+        s_prefix = (prefix << 8) | 255ULL;
+      }
     }
     __syncthreads();
   }
@@ -151,16 +191,8 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
   const int i0 = tid * chunk, i1 = min(n, i0 + chunk);
   int c_eq = 0;
   for (int i = i0; i < i1; ++i) c_eq += keys[i] == kth;
-  scan_a[tid] = c_eq;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; ++t) {
-      int v = scan_a[t];
-      scan_a[t] = run;
-      run += v;
-    }
-  }
+  int tot_unused;
+  scan_a[tid] = block_excl_scan256(c_eq, wsum, &tot_unused);
   __syncthreads();
   int eq_rank = scan_a[tid];
   int c_sel = 0;
@@ -173,16 +205,7 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
       ++eq_rank;
     }
   }
-  scan_b[tid] = c_sel;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; ++t) {
-      int v = scan_b[t];
-      scan_b[t] = run;
-      run += v;
-    }
-  }
+  scan_b[tid] = block_excl_scan256(c_sel, wsum, &tot_unused);
   __syncthreads();
   {
     int pos = scan_b[tid];
@@ -202,11 +225,36 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
       }
     }
   }
-  __syncthreads();
+  if (tid == 0) nsel_g[blk] = n_sel;
+}
 
-  // ---- 3. k-means restarts, one lane each ------------------------------------------------
-  if (tid < n_init) {
-    const uint64_t init = (uint64_t)tid;
+// ---- 3. k-means restarts: one THREAD per (cloud-anchor, restart).  Inside the fused kernel this phase
+// ran on 10 lanes of one wave while the workgroup's other 246 threads waited; here every lane works.
+__global__ __launch_bounds__(256) void k_symcut_kmeans(const int32_t* __restrict__ Ks, int n_anchor,
+                                                       int n_blk, int n_init, int max_iter, uint64_t seed,
+                                                       const double* __restrict__ pts_g,
+                                                       const int32_t* __restrict__ nsel_g,
+                                                       double* __restrict__ km_centers_g,
+                                                       double* __restrict__ km_inertia_g) {
+  __shared__ double pts_s[8][SYM_MAX_NN][3];  // the points of the (up to 8) cloud-anchors of this workgroup
+  const int per = 256 / n_init < 8 ? 256 / n_init : 8;  // cloud-anchors per workgroup
+  const int tid = threadIdx.x;
+  const int sub = tid / n_init;                          // which of them this thread works on
+  const int blk = blockIdx.x * per + sub;
+  for (int i = tid; i < per * SYM_MAX_NN * 3; i += 256) {
+    const int sb = i / (SYM_MAX_NN * 3);
+    const int64_t gb = (int64_t)blockIdx.x * per + sb;
+    (&pts_s[0][0][0])[i] = gb < n_blk ? pts_g[gb * SYM_MAX_NN * 3 + (i - sb * SYM_MAX_NN * 3)] : 0.0;
+  }
+  __syncthreads();
+  if (sub >= per || blk >= n_blk) return;
+  const int n_sel = nsel_g[blk];
+  if (n_sel == 0) return;
+  const int K = Ks[blk / n_anchor];
+  double (*pts)[3] = pts_s[sub];
+  const int init_id = tid - sub * n_init;
+  {
+    const uint64_t init = (uint64_t)init_id;
     KmState st;
 #pragma unroll
     for (int c = 0; c < 4; ++c) st.cx[c] = st.cy[c] = st.cz[c] = 0.0;
@@ -295,14 +343,36 @@ __global__ __launch_bounds__(256) void k_symcut_fit(
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      km_centers[tid][3 * c + 0] = st.cx[c];
-      km_centers[tid][3 * c + 1] = st.cy[c];
-      km_centers[tid][3 * c + 2] = st.cz[c];
+      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 0] = st.cx[c];
+      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 1] = st.cy[c];
+      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 2] = st.cz[c];
     }
-    km_inertia[tid] = inertia;
-  }
-  __syncthreads();
+    km_inertia_g[(int64_t)blk * n_init + init_id] = inertia;
+    }
+}
 
+template <int DIM>
+__global__ __launch_bounds__(256) void k_symcut_finish(
+    const float* __restrict__ xyz, const int64_t* __restrict__ off, int n_anchor,
+    const int32_t* __restrict__ Ks, int n_init, const double* __restrict__ pts_g,
+    const int32_t* __restrict__ nsel_g, const double* __restrict__ km_centers_g,
+    const double* __restrict__ km_inertia_g, double* __restrict__ out_centers,
+    int32_t* __restrict__ out_counts, double* __restrict__ out_min_cdist,
+    double* __restrict__ out_max_err) {
+  __shared__ double sel_centers[12];
+  __shared__ int counts[4];
+  const int blk = blockIdx.x;
+  const int cloud = blk / n_anchor;
+  const int tid = threadIdx.x;
+  const int n_sel = nsel_g[blk];
+  if (n_sel == 0) return;  // degenerate: outputs written by k_symcut_select
+  const int64_t base = off[cloud];
+  const int n = (int)(off[cloud + 1] - base);
+  const int K = Ks[cloud];
+  double* oc = out_centers + (int64_t)blk * 12;
+  const double (*pts)[3] = reinterpret_cast<const double (*)[3]>(pts_g + (int64_t)blk * SYM_MAX_NN * 3);
+  const double (*km_centers)[12] = reinterpret_cast<const double (*)[12]>(km_centers_g + (int64_t)blk * n_init * 12);
+  const double* km_inertia = km_inertia_g + (int64_t)blk * n_init;
   // ---- 4. best restart + gate statistics -----------------------------------------------------
   if (tid == 0) {
     int best = 0;
@@ -435,7 +505,10 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
   PoolBuf<int64_t> d_off(n_cloud + 1), d_koff(n_cloud + 1);
   PoolBuf<int32_t> d_K(n_cloud);
   PoolBuf<unsigned long long> keys((size_t)key_off[n_cloud] * n_anchor + 1);
-  CS_REQUIRE(d_off.p && d_koff.p && d_K.p && keys.p, CS_ERR_HIP,
+  const size_t n_ca = (size_t)n_cloud * n_anchor;
+  PoolBuf<double> pts_g(n_ca * SYM_MAX_NN * 3), kmc_g(n_ca * n_init * 12), kmi_g(n_ca * n_init);
+  PoolBuf<int32_t> nsel_g(n_ca);
+  CS_REQUIRE(d_off.p && d_koff.p && d_K.p && keys.p && pts_g.p && kmc_g.p && kmi_g.p && nsel_g.p, CS_ERR_HIP,
              "cs_symcut_fit: scratch allocation failed");
   CS_HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), sizeof(int64_t) * (n_cloud + 1),
                               hipMemcpyHostToDevice, s));
@@ -444,15 +517,22 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
   CS_HIP_CHECK(hipMemcpyAsync(d_K.p, Ks.data(), sizeof(int32_t) * n_cloud, hipMemcpyHostToDevice, s));
   {
     ProfScope prof("symcut", s);
-    dim3 grid((unsigned)(n_cloud * n_anchor));
+    const int n_blk = n_cloud * n_anchor;
+    dim3 grid((unsigned)n_blk);
     if (dim == 16)
-      hipLaunchKernelGGL((k_symcut_fit<16>), grid, dim3(256), 0, s, d_feat, d_xyz, d_off.p,
+      hipLaunchKernelGGL((k_symcut_select<16>), grid, dim3(256), 0, s, d_feat, d_xyz, d_off.p,
                          d_anchor, n_anchor, d_K.p, n_nn, n_init, max_iter, seed, keys.p,
-                         d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error);
+                         d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error, pts_g.p, nsel_g.p);
     else
-      hipLaunchKernelGGL((k_symcut_fit<32>), grid, dim3(256), 0, s, d_feat, d_xyz, d_off.p,
+      hipLaunchKernelGGL((k_symcut_select<32>), grid, dim3(256), 0, s, d_feat, d_xyz, d_off.p,
                          d_anchor, n_anchor, d_K.p, n_nn, n_init, max_iter, seed, keys.p,
-                         d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error);
+                         d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error, pts_g.p, nsel_g.p);
+    const int per = 256 / n_init < 8 ? 256 / n_init : 8;
+    hipLaunchKernelGGL(k_symcut_kmeans, dim3((unsigned)((n_blk + per - 1) / per)), dim3(256), 0, s, d_K.p,
+                       n_anchor, n_blk, n_init, max_iter, seed, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p);
+    hipLaunchKernelGGL((k_symcut_finish<16>), grid, dim3(256), 0, s, d_xyz, d_off.p, n_anchor, d_K.p,
+                       n_init, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, d_centers, d_counts,
+                       d_min_center_dist, d_max_error);
     CS_LAUNCH_CHECK();
   }
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order

@@ -158,14 +158,18 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
         sel0 = np.zeros((P, 4, 3))
         sel1 = np.zeros((P, 4, 3))
         if cand:
-            def fit(feat, xyz, off, anc):
-                a = torch.from_numpy(np.stack([anc[p] if anc[p] is not None
-                                               else np.zeros(n_anchor, np.int32) for p in range(P)])).to(dev)
-                c, cnt, mcd, mer = B.symcut_fit(feat, xyz, off, a, Ks, 50, 10, 300, 0)
-                return c.cpu().numpy(), cnt.cpu().numpy(), mcd.cpu().numpy(), mer.cpu().numpy()
+            # one launch set for both sides (query clouds, then CAD clouds): the k-means stage is
+            # latency-bound (one thread per restart), twice the clouds cost the same time
+            def anchors_of(anc):
+                return np.stack([anc[p] if anc[p] is not None else np.zeros(n_anchor, np.int32) for p in range(P)])
 
-            c0, cnt0, mcd0, mer0 = fit(baseF, xyz0, off0, anc0)
-            c1, cnt1, mcd1, mer1 = fit(posF, xyz1, off1, anc1)
+            a_all = torch.from_numpy(np.concatenate([anchors_of(anc0), anchors_of(anc1)])).to(dev)
+            off_all = off0 + [off0[-1] + o for o in off1[1:]]
+            c, cnt, mcd, mer = B.symcut_fit(torch.cat([baseF, posF]), torch.cat([xyz0, xyz1]), off_all, a_all,
+                                            Ks + Ks, 50, 10, 300, 0)
+            c, cnt, mcd, mer = c.cpu().numpy(), cnt.cpu().numpy(), mcd.cpu().numpy(), mer.cpu().numpy()
+            c0, cnt0, mcd0, mer0 = c[:P], cnt[:P], mcd[:P], mer[:P]
+            c1, cnt1, mcd1, mer1 = c[P:], cnt[P:], mcd[P:], mer[P:]
             g0, ok0 = gate_and_order_batch(c0, cnt0, mcd0, mer0, n0, Ks, cand, force_gate)
             g1, ok1 = gate_and_order_batch(c1, cnt1, mcd1, mer1, n1, Ks, cand, force_gate)
             ok = ok0 & ok1
