@@ -803,6 +803,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
 // Survivors: hypotheses whose upper bound reaches the carried best count.  The others get count 0.
 __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const int32_t* __restrict__ cnt_up,
                                    int it0, int bcount, int bmax, int32_t* __restrict__ res_cnt,
+                                   unsigned long long* __restrict__ err_by_h,
                                    int32_t* __restrict__ hlist, int32_t* __restrict__ n_surv) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -813,6 +814,7 @@ __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const i
   if (cnt_up[(int64_t)p * bmax + h] >= pr.best_cnt) {
     const int slot = atomicAdd(&n_surv[p], 1);
     hlist[(int64_t)p * bmax + slot] = h;
+    err_by_h[(int64_t)p * bmax + h] = 0;  // accumulated by k_ransac_count_few
   }
 }
 
@@ -831,10 +833,13 @@ __global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const
   atomicAdd(&stats[2], (unsigned long long)(u - e > 0 ? u - e : 0));
 }
 
-// Exact counts when only a handful of hypotheses survive the prefilter (the normal case: ~2 per
-// problem and round): one workgroup per survivor walks the pairs with the canonical f32 chain.  The
-// MFMA list kernel above needs a 128-hypothesis tile per workgroup and costs ~110 us per round even for
-// two survivors; this one ~15 us.  grid: x = survivor slots (strided), y = problem.
+// Exact counts (and fixed-point errors) when only a handful of hypotheses survive the prefilter (the
+// normal case: ~2 per problem and round).  The MFMA list kernel above needs a 128-hypothesis tile per
+// workgroup and costs ~110 us per round even for two survivors.  Here the pair range of a problem is
+// split over gridDim.x workgroups, each walks its slice once per survivor with the canonical f32
+// chain; integer partial sums are combined with atomics (exact, order-free).
+// grid: x = pair slice, y = problem, z = survivor slot (strided).  res_cnt / err_by_h of the survivors
+// are zero on entry.
 __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __restrict__ probs,
                                                           const float* __restrict__ pk, int64_t total,
                                                           const float* __restrict__ hyp, int bmax,
@@ -843,14 +848,30 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
                                                           unsigned long long* __restrict__ err_by_h,
                                                           const int32_t* __restrict__ hlist,
                                                           const int32_t* __restrict__ n_surv) {
-  __shared__ int red[4];
-  __shared__ unsigned long long rede[4];
   const int p = blockIdx.y;
   const RansacProb pr = probs[p];
   if (pr.done) return;
   const int nlist = n_surv[p];
+  if ((int)blockIdx.z >= nlist) return;
   const int tid = threadIdx.x;
-  for (int c = blockIdx.x; c < nlist; c += gridDim.x) {
+  const int per = (pr.m + gridDim.x - 1) / gridDim.x;
+  const int i0 = blockIdx.x * per, i1 = min(pr.m, i0 + per);
+  if (i0 >= i1) return;
+  // this thread's pairs stay in registers across the survivors (slices are short: m / gridDim.x / 256)
+  constexpr int MAXP = 8;
+  const bool in_regs = per <= 256 * MAXP;
+  float ps[MAXP][6];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int i = i0 + tid + 256 * j;
+      const int64_t g = pr.off + (i < i1 ? i : i0);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) ps[j][c] = pk[(int64_t)c * total + g];
+      if (i >= i1) ps[j][3] = 1.0e30f;  // far-away target: never an inlier
+    }
+  }
+  for (int c = blockIdx.z; c < nlist; c += gridDim.z) {
     const int h = hlist[(int64_t)p * bmax + c];
     const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
     float R[12];
@@ -858,17 +879,25 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
     for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
     int cnt = 0;
     unsigned long long err = 0;  // fixed-point squared error of the inliers (exact integer sum, as k_ransac_err)
-    for (int i = tid; i < pr.m; i += 256) {
-      const int64_t g = pr.off + i;
-      const float sx = pk[0 * total + g], sy = pk[1 * total + g], sz = pk[2 * total + g];
+    auto one = [&](float sx, float sy, float sz, float qx, float qy, float qz) {
       // same chain as the MFMA pair: fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q))))
-      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -pk[3 * total + g]))) + R[3];
-      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -pk[4 * total + g]))) + R[7];
-      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -pk[5 * total + g]))) + R[11];
+      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -qx))) + R[3];
+      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -qy))) + R[7];
+      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -qz))) + R[11];
       const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
       if (d2 < thr2) {
         ++cnt;
         err += (unsigned long long)(uint32_t)(d2 * scale);
+      }
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j) one(ps[j][0], ps[j][1], ps[j][2], ps[j][3], ps[j][4], ps[j][5]);
+    } else {
+      for (int i = i0 + tid; i < i1; i += 256) {
+        const int64_t g = pr.off + i;
+        one(pk[0 * total + g], pk[1 * total + g], pk[2 * total + g], pk[3 * total + g], pk[4 * total + g],
+            pk[5 * total + g]);
       }
     }
 #pragma unroll
@@ -876,16 +905,10 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
       cnt += __shfl_xor(cnt, off);
       err += __shfl_xor(err, off);
     }
-    if ((tid & 63) == 0) {
-      red[tid >> 6] = cnt;
-      rede[tid >> 6] = err;
+    if ((tid & 63) == 0 && cnt) {
+      atomicAdd(&res_cnt[(int64_t)p * bmax + h], cnt);
+      atomicAdd(&err_by_h[(int64_t)p * bmax + h], err);
     }
-    __syncthreads();
-    if (tid == 0) {
-      res_cnt[(int64_t)p * bmax + h] = red[0] + red[1] + red[2] + red[3];
-      err_by_h[(int64_t)p * bmax + h] = rede[0] + rede[1] + rede[2] + rede[3];
-    }
-    __syncthreads();
   }
 }
 
@@ -1340,7 +1363,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                         dim3(256), 0, s, d_probs, cnt_up.p, it0, b, bmax, res_cnt.p, hlist.p, d_nsurv);
+                         dim3(256), 0, s, d_probs, cnt_up.p, it0, b, bmax, res_cnt.p, cand_err.p, hlist.p,
+                         d_nsurv);
       // exact counts of the survivors; few hypotheses, so the pair range is split finely
       int lsplits = 16;
       while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
@@ -1348,7 +1372,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         ProfScope prof("ransac_eval", s);
         // the previous round's survivor counts pick the kernel (both are exact for any count)
         if (max_surv_prev <= 32) {
-          hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
+          hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob, 8), dim3(256), 0, s, d_probs, pk.p,
                              tot1, hyp.p, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;
         } else {
