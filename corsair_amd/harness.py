@@ -56,7 +56,7 @@ class EmbeddedSet:
         new_off = np.concatenate([[0], np.cumsum(lens)])
         starts = torch.from_numpy(off[ids] - new_off[:-1]).to(dev)
         rows = torch.arange(int(new_off[-1]), device=dev) + torch.repeat_interleave(
-            starts, torch.from_numpy(lens).to(dev))
+            starts, torch.from_numpy(lens).to(dev), output_size=int(new_off[-1]))
         return EmbeddedSet(self.F[rows], self.origin[rows], new_off.tolist(),
                            self.desc[torch.from_numpy(ids).to(dev)])
 

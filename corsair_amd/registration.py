@@ -136,9 +136,11 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
 
     # ---- 1. vanilla correspondences (find_kcorr, utils/eval_pose.py:48-79) -----------------
     nn = B.knn_feat(baseF, off0, posF, off1, k)                     # [N0, k] local CAD rows
+    # (output_size given: repeat_interleave with tensor repeats otherwise reads the total back to the
+    # host, a synchronisation in the middle of the launch sequence)
     toff_rows = torch.repeat_interleave(
         torch.tensor(off1[:-1], device=dev, dtype=torch.int64),
-        torch.tensor(n0, device=dev, dtype=torch.int64))            # CAD segment start per query row
+        torch.tensor(n0, device=dev, dtype=torch.int64), output_size=off0[-1])  # CAD segment start per query row
     tgt_rows = (nn.to(torch.int64) + toff_rows[:, None]).reshape(-1)
     src_rows = torch.arange(off0[-1], device=dev, dtype=torch.int64).repeat_interleave(k)
     prob_src = [src_rows]
@@ -191,7 +193,8 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             # The labelled search runs on the partitioned rows, so a wave of 64 queries shares one
             # label and skips the targets of the other parts wholesale.
             seg_rows = torch.repeat_interleave(torch.arange(P, device=dev, dtype=torch.int64),
-                                               torch.tensor(n0, device=dev, dtype=torch.int64))
+                                               torch.tensor(n0, device=dev, dtype=torch.int64),
+                                               output_size=off0[-1])
             sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
             nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
                                 qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
@@ -211,15 +214,16 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
                 L = torch.from_numpy(lens[keep]).to(dev)
                 total = int(lens[keep].sum())
                 seg_first = torch.cumsum(L, 0) - L
-                base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(seg_first, L)
+                base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(
+                    seg_first, L, output_size=total)
                 q_first = torch.tensor([off0[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
                 n_first = torch.from_numpy(row_start[:-1][keep]).to(dev)
                 t_first = torch.tensor([off1[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
-                q_rows = torch.repeat_interleave(q_first, L) + base
-                n_rows = torch.repeat_interleave(n_first, L) + base
+                q_rows = torch.repeat_interleave(q_first, L, output_size=total) + base
+                n_rows = torch.repeat_interleave(n_first, L, output_size=total) + base
                 prob_src.append(sorted_rows[q_rows].repeat_interleave(k))
                 prob_tgt.append((nn_cfg[n_rows].to(torch.int64)
-                                 + torch.repeat_interleave(t_first, L)[:, None]).reshape(-1))
+                                 + torch.repeat_interleave(t_first, L, output_size=total)[:, None]).reshape(-1))
                 for j in keep:
                     prob_len.append(n0[cfg_pair[j]] * k)
                     prob_pair.append(cfg_pair[j])
