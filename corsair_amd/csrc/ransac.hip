@@ -65,10 +65,14 @@ __host__ __device__ static inline uint32_t rng_index(uint64_t seed, uint64_t itr
 }
 
 // structure-of-arrays copy of the correspondences: pk[c * total + i], c = sx,sy,sz,qx,qy,qz
+// + pair32[i] = (sx, sy, sz, qx | qy, qz, 0, 0): one aligned 32-B sector per pair for the random
+// sampling of k_ransac_hyp (two 12-B rows of the caller's arrays would touch two to four lines)
 __global__ void k_ransac_pack(const float* __restrict__ src, const float* __restrict__ tgt,
-                              int64_t n, float* __restrict__ pk) {
+                              int64_t n, float* __restrict__ pk, float4* __restrict__ pair32) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  pair32[2 * i + 0] = make_float4(src[3 * i + 0], src[3 * i + 1], src[3 * i + 2], tgt[3 * i + 0]);
+  pair32[2 * i + 1] = make_float4(tgt[3 * i + 1], tgt[3 * i + 2], 0.f, 0.f);
   pk[0 * n + i] = src[3 * i + 0];
   pk[1 * n + i] = src[3 * i + 1];
   pk[2 * n + i] = src[3 * i + 2];
@@ -125,8 +129,7 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
 
 // hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
 __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict__ probs,
-                                                    const float* __restrict__ src,
-                                                    const float* __restrict__ tgt, int it0,
+                                                    const float4* __restrict__ pair32, int it0,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed,
                                                     const int32_t* __restrict__ xcd_prob, int slots,
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
   double cs_[3] = {0, 0, 0}, ct_[3] = {0, 0, 0};
   for (int j = 0; j < ransac_n; ++j) {
     const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    // sampled rows are read from the caller's [M,3] arrays (12-byte rows: one or two lines each)
-    cs_[0] += (double)src[3 * i + 0];
-    cs_[1] += (double)src[3 * i + 1];
-    cs_[2] += (double)src[3 * i + 2];
-    ct_[0] += (double)tgt[3 * i + 0];
-    ct_[1] += (double)tgt[3 * i + 1];
-    ct_[2] += (double)tgt[3 * i + 2];
+    const float4 a = pair32[2 * i], b = pair32[2 * i + 1];  // one 32-B sector
+    cs_[0] += (double)a.x;
+    cs_[1] += (double)a.y;
+    cs_[2] += (double)a.z;
+    ct_[0] += (double)a.w;
+    ct_[1] += (double)b.x;
+    ct_[2] += (double)b.y;
   }
   const double dn = (double)ransac_n;
 #pragma unroll
@@ -164,10 +167,9 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
   double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int j = 0; j < ransac_n; ++j) {
     const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    const double ds[3] = {(double)src[3 * i + 0] - cs_[0], (double)src[3 * i + 1] - cs_[1],
-                          (double)src[3 * i + 2] - cs_[2]};
-    const double dt[3] = {(double)tgt[3 * i + 0] - ct_[0], (double)tgt[3 * i + 1] - ct_[1],
-                          (double)tgt[3 * i + 2] - ct_[2]};
+    const float4 a = pair32[2 * i], b = pair32[2 * i + 1];
+    const double ds[3] = {(double)a.x - cs_[0], (double)a.y - cs_[1], (double)a.z - cs_[2]};
+    const double dt[3] = {(double)a.w - ct_[0], (double)b.x - ct_[1], (double)b.y - ct_[2]};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1209,10 +1211,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   char* const h_state = pinned_scratch(st_bytes);
   CS_REQUIRE(state.p && h_state, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   PoolBuf<float> pk((size_t)tot1 * 6);
+  PoolBuf<float4> pair32((size_t)tot1 * 2);
   PoolBuf<float> hyp((size_t)n_prob * 12 * bmax);
   PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax), cand((size_t)n_prob * bmax);
   PoolBuf<unsigned long long> cand_err((size_t)n_prob * bmax);
-  CS_REQUIRE(pk.p && hyp.p && res_cnt.p && cand.p && cand_err.p,
+  CS_REQUIRE(pk.p && pair32.p && hyp.p && res_cnt.p && cand.p && cand_err.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   const bool pf_alloc = use_pf && max_iter > pf_from;
   // f16 pair image: every problem padded to whole LDS stages
@@ -1237,7 +1240,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
     hipLaunchKernelGGL(k_ransac_pack, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
-                       d_src, d_tgt, total, pk.p);
+                       d_src, d_tgt, total, pk.p, pair32.p);
     CS_LAUNCH_CHECK();
   }
   if (pf_alloc) {
@@ -1276,7 +1279,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     ProfScope prof("ransac_hyp", s);
     const int htiles = (count + 255) / 256;
     hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
-                       d_src, d_tgt, first, count, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
+                       pair32.p, first, count, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
   };
   int it0 = 0;
   while (it0 < max_iter) {
