@@ -156,6 +156,23 @@ __global__ void k_seg_keys(const int64_t* __restrict__ off, int n_seg, const int
   }
 }
 
+// lab_start[seg * 10 + l] = first row (label order, local to the segment) whose label key is >= l,
+// l = 0..9 (keys: 0..7 parts, 8 = no part); one thread per entry, binary search in the sorted keys
+__global__ void k_label_starts(const int64_t* __restrict__ off, int n_seg,
+                               const uint32_t* __restrict__ keys_sorted, int32_t* __restrict__ lab_start) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_seg * 10) return;
+  const int sg = i / 10, l = i - sg * 10;
+  const int64_t b = off[sg], e = off[sg + 1];
+  const uint32_t key = (uint32_t)sg * 16u + (uint32_t)l;
+  int64_t lo = b, hi = e;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  lab_start[i] = (int32_t)(lo - b);
+}
+
 __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ work,
                                                     const float* __restrict__ qf,
                                                     const float* __restrict__ tf,
@@ -165,12 +182,14 @@ __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ 
                                                     const int32_t* __restrict__ tlabel,
                                                     const int32_t* __restrict__ perm,
                                                     const int32_t* __restrict__ torder,
+                                                    const int32_t* __restrict__ lab_start,
                                                     int32_t* __restrict__ cand_i) {
   // double-buffered stage: features (f32, converted when the fragment is read), |t|^2, label, row id
   __shared__ float t_lds[2][KNM_TT * KNM_PITCH];
   __shared__ double tn_lds[2][KNM_TT];
   __shared__ int32_t tl_lds[2][KNM_TT];
   __shared__ int32_t ti_lds[2][KNM_TT];
+  __shared__ int32_t wrange[2][4];
   const KnnWork wk = work[blockIdx.x];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -188,8 +207,10 @@ __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ 
     qvalid[g] = qloc < wk.qn;
     const int64_t qrow = wk.q0 + (qvalid[g] ? qloc : 0);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) qb[g][s4] = (double)qf[qrow * 16 + 4 * s4 + kq];  // B[k = 4 s + kq][query]
-    my_qn[g] = qnorm[qrow];
+    // B[k = 4 s + kq][query], pre-scaled by -2 (exact): with the accumulator preloaded with |t|^2 the
+    // chain delivers |t|^2 - 2 q.t, the ranking value of the query (|q|^2 is the same for all targets)
+    for (int s4 = 0; s4 < 4; ++s4) qb[g][s4] = -2.0 * (double)qf[qrow * 16 + 4 * s4 + kq];
+    my_qn[g] = 0.0;
     want[g] = -1;
     if (use_labels) {
       const int ql = qlabel[qrow];
@@ -208,6 +229,24 @@ __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ 
   // lane's threshold is only appended (a register shift); the pending lists of the whole wave are
   // ranked together when one of them is full.  Ranking on every hit would run the 8-slot insertion
   // for nearly every element, because some lane of the 64 almost always has a hit.
+  // Labelled search: targets are visited in label order, and the queries of a workgroup (sorted by
+  // part) want only one or two labels: the scan covers just the target rows of those labels.
+  int t_lo = 0, t_hi = wk.tn;
+  if (use_labels && lab_start != nullptr) {
+    if (lane == 0) {
+      wrange[0][wave] = wmin;
+      wrange[1][wave] = wmax;
+    }
+    __syncthreads();
+    const int bmin = min(min(wrange[0][0], wrange[0][1]), min(wrange[0][2], wrange[0][3]));
+    const int bmax = max(max(wrange[1][0], wrange[1][1]), max(wrange[1][2], wrange[1][3]));
+    if (bmin > bmax) {
+      t_hi = 0;  // no query of this workgroup has a part
+    } else {
+      t_lo = lab_start[wk.pad * 10 + bmin];
+      t_hi = lab_start[wk.pad * 10 + bmax + 1];
+    }
+  }
   double bd[KNM_NG][KNM_KK], pd[KNM_NG][KNM_PEND];
   int32_t bi[KNM_NG][KNM_KK], pi[KNM_NG][KNM_PEND];
   int pn[KNM_NG];
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ 
   int32_t sl, si;
   auto stage_load = [&](int tbase) {
     const int j = tid;
-    const bool ok = tbase + j < wk.tn;
+    const bool ok = tbase + j < t_hi;
     const int src = ok ? (torder ? torder[wk.t0 + tbase + j] : tbase + j) : 0;
     const float4* rp = reinterpret_cast<const float4*>(tf + (wk.t0 + src) * 16);
 #pragma unroll
@@ -276,54 +315,69 @@ __global__ __launch_bounds__(256) void k_knn_mfma16(const KnnWork* __restrict__ 
     tl_lds[b][tid] = sl;
     ti_lds[b][tid] = si;
   };
-  if (wk.tn > 0) {
-    stage_load(0);
+  double thr = INFINITY;  // pruning threshold of the lane's query (see the ranking step below)
+  if (t_hi > t_lo) {
+    stage_load(t_lo);
     stage_store(0);
   }
   __syncthreads();
   int buf = 0;
-  for (int tbase = 0; tbase < wk.tn; tbase += KNM_TT) {
-    const int tcount = min(KNM_TT, wk.tn - tbase);
-    const bool more = tbase + KNM_TT < wk.tn;
+  for (int tbase = t_lo; tbase < t_hi; tbase += KNM_TT) {
+    const int tcount = min(KNM_TT, t_hi - tbase);
+    const bool more = tbase + KNM_TT < t_hi;
     if (more) stage_load(tbase + KNM_TT);  // global loads in flight during the tiles below
-    for (int t = 0; t < (tcount + 15) / 16; ++t) {
-      if (use_labels) {
-        // label order: the tile's labels span [first, last]
-        const int l0 = tl_lds[buf][16 * t], l1 = tl_lds[buf][min(16 * t + 15, tcount - 1)];
-        if (l1 < wmin || l0 > wmax) continue;  // wave-uniform
-      }
+    // two 16-row tiles per iteration: their MFMA chains are independent, so the second chain issues
+    // while the first drains, and the LDS reads of both are in flight together (rows past tcount carry
+    // |t|^2 = +inf and never enter a shortlist)
+    static_assert(KNM_NG == 1, "the two-tile loop below is written for one query group per wave");
+    for (int t = 0; t < (tcount + 15) / 16; t += 2) {
       const float* ap = &t_lds[buf][(16 * t + col) * KNM_PITCH + kq];
-      double a[4];
+      double a0[4], a1[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) a[s4] = (double)ap[4 * s4];  // A[target row][k = 4 s + kq]
-      double tn4[4];
-      int tl4[4];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        a0[s4] = (double)ap[4 * s4];                        // A[target row][k = 4 s + kq]
+        a1[s4] = (double)ap[16 * KNM_PITCH + 4 * s4];
+      }
+      f64x4 acc0, acc1;
+      int tl0[4], tl1[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        tn4[r] = tn_lds[buf][16 * t + kq + 4 * r];
-        tl4[r] = tl_lds[buf][16 * t + kq + 4 * r];
+        acc0[r] = tn_lds[buf][16 * t + kq + 4 * r];
+        acc1[r] = tn_lds[buf][16 * t + 16 + kq + 4 * r];
+        tl0[r] = tl_lds[buf][16 * t + kq + 4 * r];
+        tl1[r] = tl_lds[buf][16 * t + 16 + kq + 4 * r];
       }
 #pragma unroll
-      for (int g = 0; g < KNM_NG; ++g) {
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int s4 = 0; s4 < 4; ++s4) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], qb[0][s4], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], qb[0][s4], acc1, 0, 0, 0);
+      }
+      // acc[r] = |t|^2 - 2 q.t for target row 16 t (+16) + kq + 4 r and the lane's query
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], qb[g][s4], acc, 0, 0, 0);
-        // acc[r] = dot(target row 16 t + kq + 4 r, query col of group g)
+      for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double dist = fma(-2.0, acc[r], my_qn[g] + tn4[r]);
-          if (use_labels && tl4[r] != want[g]) dist = INFINITY;
-          if (dist < bd[g][KNM_KK - 1]) {
+          double dist = u ? acc1[r] : acc0[r];
+          if (use_labels && (u ? tl1[r] : tl0[r]) != want[0]) dist = INFINITY;
+          if (dist < thr) {
 #pragma unroll
             for (int e = KNM_PEND - 1; e > 0; --e) {
-              pd[g][e] = pd[g][e - 1];
-              pi[g][e] = pi[g][e - 1];
+              pd[0][e] = pd[0][e - 1];
+              pi[0][e] = pi[0][e - 1];
             }
-            pd[g][0] = dist;
-            pi[g][0] = ti_lds[buf][16 * t + kq + 4 * r];
-            ++pn[g];
+            pd[0][0] = dist;
+            pi[0][0] = ti_lds[buf][16 * t + 16 * u + kq + 4 * r];
+            ++pn[0];
           }
-          if (__any(pn[g] == KNM_PEND)) rank_pending(g);
+          if (__any(pn[0] == KNM_PEND)) {
+            rank_pending(0);
+            // The four lanes of a query (kq = 0..3) scan disjoint quarters of the targets.  Whichever of
+            // them already holds KNM_KK candidates below tau bounds the query's KNM_KK-th best by tau,
+            // so all four may prune with the smallest of their KNM_KK-th values.
+            thr = bd[0][KNM_KK - 1];
+            thr = fmin(thr, __shfl_xor(thr, 16));
+            thr = fmin(thr, __shfl_xor(thr, 32));
+          }
         }
       }
     }
@@ -927,7 +981,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
       w.qn = (int32_t)(qn - q < qtile ? qn - q : qtile);
       w.tn = (int32_t)tn;
       w.prob = p;
-      w.pad = 0;
+      w.pad = h_tseg[p];  // target segment (label-order tables of the MFMA path)
       work.push_back(w);
     }
     out_row += qn;
@@ -946,7 +1000,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
     PoolBuf<int32_t> cand((size_t)(out_row ? out_row : 1) * 4 * KNM_KK);
     PoolBuf<int32_t> torder;
     PoolBuf<uint32_t> keys, keys_sorted;
-    PoolBuf<int32_t> rows_in;
+    PoolBuf<int32_t> rows_in, lab_start;
     PoolBuf<int64_t> dtoff;
     PoolBuf<char> tmp;
     CS_REQUIRE(qnorm.p && tnorm.p && cand.p, CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
@@ -974,12 +1028,15 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
       CS_REQUIRE(tmp.alloc(tmp_bytes ? tmp_bytes : 1), CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
       CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_sorted.p, rows_in.p,
                                                       torder.p, (int)nt_rows, 0, end_bit, s));
+      CS_REQUIRE(lab_start.alloc((size_t)ntseg * 10), CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      hipLaunchKernelGGL(k_label_starts, dim3((unsigned)ceil_div((int64_t)ntseg * 10, 256)), dim3(256), 0, s,
+                         dtoff.p, ntseg, keys_sorted.p, lab_start.p);
     }
     {
       ProfScope prof("knn", s, knn_flop);
       hipLaunchKernelGGL(k_knn_mfma16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_qf, d_tf,
                          qnorm.p, tnorm.p, d_qlabel, d_tlabel, d_perm, d_tlabel ? torder.p : nullptr,
-                         cand.p);
+                         d_tlabel ? lab_start.p : nullptr, cand.p);
       hipLaunchKernelGGL(k_knn_rescore16, dim3((unsigned)work.size()), dim3(KNM_QT), 0, s, dwork.p, d_qf,
                          d_tf, cand.p, k, d_idx, d_dist);
       CS_LAUNCH_CHECK();
