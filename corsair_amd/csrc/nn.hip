@@ -12,6 +12,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -42,7 +43,12 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
                                                   const int32_t* __restrict__ tlabel,
                                                   const int32_t* __restrict__ perm,
                                                   int32_t* __restrict__ out_idx,
-                                                  double* __restrict__ out_dist) {
+                                                  double* __restrict__ out_dist,
+                                                  const int32_t* __restrict__ tile_flag,
+                                                  const int32_t* __restrict__ qflag) {
+  // fallback mode (k_knn_rescore_f16 flagged some queries): only flagged tiles run, only flagged
+  // queries are written
+  if (tile_flag && !tile_flag[blockIdx.x]) return;
   // targets are converted to f64 once per tile (the inner loop is f64-VALU bound: one v_cvt less
   // per dimension and pair)
   __shared__ double t_lds[KNN_TT * DIM];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void k_knn_feat(const KnnWork* __restrict__ wo
       }
     }
   }
-  if (active) {
+  if (active && (!qflag || qflag[wk.o0 + tid])) {
     for (int j = 0; j < k; ++j) {
       // (unrolled select keeps bd/bi in registers)
       double dj = INFINITY;
@@ -457,6 +463,387 @@ __global__ void k_knn_rescore16(const KnnWork* __restrict__ work, const float* _
     out_idx[orow * k + j] = have ? ij : -1;
     if (out_dist) out_dist[orow * k + j] = have ? sqrt(dj) : INFINITY;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// feature k-NN shortlist on the f16 matrix cores (16-d features, k <= 6): the default path.
+// On gfx950 the f64 MFMA runs on the vector unit's double-precision ALUs (78.6 TF either way; measured:
+// the f64-MFMA kernel above cannot overlap its MFMAs with its own VALU work), so it stays ~3x above its
+// bound.  Here |t|^2 - 2 q.t is evaluated like the RANSAC prefilter: every feature is split into f16
+// hi + lo, hi*hi + lo*hi + hi*lo (48 products) is three v_mfma_f32_32x32x16_f16 per 32 x 32 tile (true
+// matrix cores, ~20x the f64 rate, co-issuing with the VALU), the accumulator is preloaded with |t|^2.
+//   rows = targets (LDS, staged by LDS-DMA from a 112-B-pitch f16 image in visiting order),
+//   cols = queries (registers): a lane owns one query and 16 of the tile's 32 target rows.
+// The result is only a SHORTLIST (2 x KNF_KK candidates per query by the approximate value).
+// k_knn_rescore_f16 re-evaluates them with the canonical f64 chain, ranks by (distance, row) and
+// VERIFIES the shortlist: every target that was not kept has an approximate value >= tau (the final
+// pruning threshold), hence an exact one >= tau - eps; if the exact k-th distance is not below that,
+// the query is flagged and recomputed by the exhaustive kernel (k_knn_feat<16>, flagged tiles only).
+// The answer therefore equals the exhaustive kernel's for every query.
+// ------------------------------------------------------------------------------------------
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int KNF_PITCH = 56;   // halfs per image row (112 B): conflict-free ds_read_b128 fragments
+constexpr int KNF_ROWS = 192;   // target rows per LDS stage (6 MFMA row tiles, 21 KiB)
+constexpr int KNF_NG = 2;       // 32-query groups per wave
+constexpr int KNF_QT = 4 * 32 * KNF_NG;  // queries per workgroup
+static_assert(KNF_QT == 256, "tiles of the f16 path and of the exhaustive fallback must coincide");
+constexpr int KNF_KK = 8;       // shortlist per lane (two lanes per query)
+constexpr int KNF_PEND = 4;
+
+__device__ __forceinline__ void knf_split(float v, _Float16* hi, _Float16* lo) {
+  const _Float16 h = (_Float16)v;
+  *hi = h;
+  *lo = (_Float16)(v - (float)h);
+}
+
+// target image: row j of the image = target (t0 + torder[t0 + j]) (or t0 + j): [th(16) | tl(16) | th(16) | 0(8)],
+// tn32 = |t|^2 (f64 chain, rounded up to f32 is not needed: the verification budget covers its rounding),
+// ti32 = row local to the segment.  seg_t2max[seg] = max |t|^2 (error budget of the verification).
+__global__ void k_knf_pack_targets(const float* __restrict__ tf, const int64_t* __restrict__ toff, int n_seg,
+                                   const int32_t* __restrict__ torder, _Float16* __restrict__ img,
+                                   float* __restrict__ tn32, int32_t* __restrict__ ti32,
+                                   unsigned* __restrict__ seg_t2max_bits) {
+  const int sg = blockIdx.y;
+  const int64_t b = toff[sg], e = toff[sg + 1];
+  float mx = 0.f;
+  for (int64_t j = b + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < e; j += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t loc = torder ? torder[j] : (int32_t)(j - b);
+    const float* f = tf + (b + loc) * 16;
+    union {
+      _Float16 h[KNF_PITCH];
+      uint4 v[7];
+    } row;
+    double n2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      _Float16 hi, lo;
+      knf_split(f[c], &hi, &lo);
+      row.h[c] = hi;
+      row.h[16 + c] = lo;
+      row.h[32 + c] = hi;
+      n2 = fma((double)f[c], (double)f[c], n2);
+    }
+#pragma unroll
+    for (int c = 48; c < KNF_PITCH; ++c) row.h[c] = (_Float16)0.0f;
+    uint4* dst = reinterpret_cast<uint4*>(img + j * KNF_PITCH);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[c] = row.v[c];
+    tn32[j] = (float)n2;
+    ti32[j] = loc;
+    mx = fmaxf(mx, (float)n2 * 1.0000002f);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&seg_t2max_bits[sg], __float_as_uint(mx));
+}
+
+// query operand rows: [-2 qh(16) | -2 qh(16) | -2 ql(16)] (scaling by 2 is exact in f16 below the range limit)
+__global__ void k_knf_pack_queries(const float* __restrict__ qf, int64_t n, _Float16* __restrict__ qrows) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  union {
+    _Float16 h[48];
+    uint4 v[6];
+  } row;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    _Float16 hi, lo;
+    knf_split(-2.0f * qf[i * 16 + c], &hi, &lo);
+    row.h[c] = hi;
+    row.h[16 + c] = hi;
+    row.h[32 + c] = lo;
+  }
+  uint4* dst = reinterpret_cast<uint4*>(qrows + i * 48);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) dst[c] = row.v[c];
+}
+
+__global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ work,
+                                                 const _Float16* __restrict__ qrows,
+                                                 const _Float16* __restrict__ img,
+                                                 const float* __restrict__ tn32,
+                                                 const int32_t* __restrict__ ti32,
+                                                 const int32_t* __restrict__ qlabel,
+                                                 const int32_t* __restrict__ perm,
+                                                 const int32_t* __restrict__ lab_start,
+                                                 int32_t* __restrict__ cand_i, float* __restrict__ cand_tau) {
+  constexpr int STAGE_BYTES = KNF_ROWS * KNF_PITCH * 2;  // 21504
+  constexpr int STAGE_KIB = STAGE_BYTES / 1024;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) float tn_s[2][KNF_ROWS];
+  __shared__ int32_t ti_s[2][KNF_ROWS];
+  __shared__ int32_t wrange[2][4];
+  const KnnWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int col = lane & 31;
+  const bool use_labels = qlabel != nullptr;
+  f16x8 bop[KNF_NG][3];
+  int want[KNF_NG];
+  bool qvalid[KNF_NG];
+  int wmin = 0x7fffffff, wmax = -2;
+#pragma unroll
+  for (int g = 0; g < KNF_NG; ++g) {
+    const int qloc = wave * 32 * KNF_NG + 32 * g + col;
+    qvalid[g] = qloc < wk.qn;
+    const int64_t qrow = wk.q0 + (qvalid[g] ? qloc : 0);
+    const _Float16* row = qrows + qrow * 48 + 8 * half;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) bop[g][m] = *reinterpret_cast<const f16x8*>(row + 16 * m);
+    want[g] = -1;
+    if (use_labels) {
+      const int ql = qlabel[qrow];
+      want[g] = (qvalid[g] && ql >= 0 && ql < 8) ? perm[wk.prob * 8 + ql] : -2;
+      if (want[g] >= 0) wmin = min(wmin, want[g]);
+      wmax = max(wmax, want[g]);
+    }
+  }
+  int lab_lo = -1, lab_hi = -1;  // label passes (one pass, label -1, without labels)
+  if (use_labels) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      wmin = min(wmin, __shfl_xor(wmin, off));
+      wmax = max(wmax, __shfl_xor(wmax, off));
+    }
+    if (lane == 0) {
+      wrange[0][wave] = wmin;
+      wrange[1][wave] = wmax;
+    }
+    __syncthreads();
+    lab_lo = min(min(wrange[0][0], wrange[0][1]), min(wrange[0][2], wrange[0][3]));
+    lab_hi = max(max(wrange[1][0], wrange[1][1]), max(wrange[1][2], wrange[1][3]));
+    if (lab_hi > 7) lab_hi = 7;
+    if (lab_lo > lab_hi) lab_hi = lab_lo - 1;  // nothing to scan
+  }
+  // ranked shortlist + pending list per lane and group (see k_knn_mfma16 for the scheme)
+  float bd[KNF_NG][KNF_KK], pd[KNF_NG][KNF_PEND], thr[KNF_NG];
+  int32_t bi[KNF_NG][KNF_KK], pi[KNF_NG][KNF_PEND];
+  int pn[KNF_NG];
+#pragma unroll
+  for (int g = 0; g < KNF_NG; ++g) {
+    pn[g] = 0;
+    thr[g] = INFINITY;
+#pragma unroll
+    for (int j = 0; j < KNF_KK; ++j) {
+      bd[g][j] = INFINITY;
+      bi[g][j] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int j = 0; j < KNF_PEND; ++j) {
+      pd[g][j] = INFINITY;
+      pi[g][j] = 0x7fffffff;
+    }
+  }
+  auto rank_pending = [&](int g) {
+#pragma unroll
+    for (int e = 0; e < KNF_PEND; ++e) {
+      float cd = pd[g][e];
+      int32_t ci = pi[g][e];
+      pd[g][e] = INFINITY;
+      if (cd < bd[g][KNF_KK - 1]) {
+        bool carry = false;
+#pragma unroll
+        for (int s2 = 0; s2 < KNF_KK; ++s2) {
+          if (carry || cd < bd[g][s2]) {
+            carry = true;
+            const float td = bd[g][s2];
+            const int32_t ti = bi[g][s2];
+            bd[g][s2] = cd;
+            bi[g][s2] = ci;
+            cd = td;
+            ci = ti;
+          }
+        }
+      }
+    }
+    pn[g] = 0;
+    // the two lanes of a query scan disjoint halves of every tile: either one's KNF_KK-th value bounds
+    // the query's KNF_KK-th best
+    float t = bd[g][KNF_KK - 1];
+    t = fminf(t, __shfl_xor(t, 32));
+    thr[g] = t;
+  };
+  const char* gimg = reinterpret_cast<const char*>(img + (int64_t)wk.t0 * KNF_PITCH) + lane * 16;
+  for (int lab = lab_lo; lab <= lab_hi; ++lab) {
+    int t_lo = 0, t_hi = wk.tn;
+    if (use_labels) {
+      if (lab_start == nullptr) break;
+      t_lo = lab_start[wk.pad * 10 + lab];
+      t_hi = lab_start[wk.pad * 10 + lab + 1];
+    }
+    if (t_hi <= t_lo) continue;
+    float thr_eff[KNF_NG];
+#pragma unroll
+    for (int g = 0; g < KNF_NG; ++g) thr_eff[g] = (!use_labels || want[g] == lab) ? thr[g] : -INFINITY;
+    auto issue_stage = [&](int b, int base) {
+      const char* gp = gimg + (int64_t)base * (KNF_PITCH * 2);
+#pragma unroll
+      for (int i = 0; i < (STAGE_KIB + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;
+        if (piece < STAGE_KIB)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024),
+                                           (__attribute__((address_space(3))) void*)(lds + b * STAGE_BYTES + piece * 1024),
+                                           16, 0, 0);
+      }
+      if (tid < KNF_ROWS) {  // |t|^2 and row ids; rows past the label's range can never be hit
+        const bool ok = base + tid < t_hi;
+        tn_s[b][tid] = ok ? tn32[wk.t0 + base + tid] : INFINITY;
+        ti_s[b][tid] = ok ? ti32[wk.t0 + base + tid] : 0x7fffffff;
+      }
+    };
+    __syncthreads();  // the previous label pass may still read the buffers
+    issue_stage(0, t_lo);
+    int buf = 0;
+    for (int base = t_lo; base < t_hi; base += KNF_ROWS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (base + KNF_ROWS < t_hi) issue_stage(buf ^ 1, base + KNF_ROWS);
+#pragma unroll 1
+      for (int t = 0; t < KNF_ROWS / 32; ++t) {
+        if (base + 32 * t >= t_hi) break;  // whole tile past the range (block-uniform)
+        const _Float16* arow =
+            reinterpret_cast<const _Float16*>(lds + buf * STAGE_BYTES) + (t * 32 + col) * KNF_PITCH + 8 * half;
+        f16x8 a[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const f16x8*>(arow + 16 * m);
+        // accumulator input: |t|^2 of the 16 rows this lane owns: (r & 3) + 8 (r >> 2) + 4 half
+        f32x16 c16;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 v = *reinterpret_cast<const float4*>(&tn_s[buf][t * 32 + 8 * q4 + 4 * half]);
+          c16[4 * q4 + 0] = v.x; c16[4 * q4 + 1] = v.y; c16[4 * q4 + 2] = v.z; c16[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int g = 0; g < KNF_NG; ++g) {
+          f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bop[g][0], c16, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bop[g][1], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bop[g][2], d, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (d[r] < thr_eff[g]) {
+#pragma unroll
+              for (int e = KNF_PEND - 1; e > 0; --e) {
+                pd[g][e] = pd[g][e - 1];
+                pi[g][e] = pi[g][e - 1];
+              }
+              pd[g][0] = d[r];
+              pi[g][0] = ti_s[buf][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+              ++pn[g];
+            }
+            if (__any(pn[g] == KNF_PEND)) {
+              rank_pending(g);
+              thr_eff[g] = (!use_labels || want[g] == lab) ? thr[g] : -INFINITY;
+            }
+          }
+        }
+      }
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < KNF_NG; ++g) {
+    rank_pending(g);
+    const int qloc = wave * 32 * KNF_NG + 32 * g + col;
+    if (qvalid[g]) {
+      const int64_t base = ((wk.o0 + qloc) * 2 + half) * KNF_KK;
+#pragma unroll
+      for (int j = 0; j < KNF_KK; ++j) cand_i[base + j] = bi[g][j];
+      if (half == 0) cand_tau[wk.o0 + qloc] = thr[g];
+    }
+  }
+}
+
+// One thread per query: canonical distances of its 2 * KNF_KK candidates, k best by (distance, row), and
+// the verification of the shortlist (see the header of this section).  flag[tile] != 0 -> k_knn_feat
+// recomputes that tile's flagged queries exhaustively.
+__global__ void k_knn_rescore_f16(const KnnWork* __restrict__ work, const float* __restrict__ qf,
+                                  const float* __restrict__ tf, const int32_t* __restrict__ cand_i,
+                                  const float* __restrict__ cand_tau,
+                                  const unsigned* __restrict__ seg_t2max_bits, int k,
+                                  int32_t* __restrict__ out_idx, double* __restrict__ out_dist,
+                                  int32_t* __restrict__ qflag, int32_t* __restrict__ tile_flag) {
+  const KnnWork wk = work[blockIdx.x];
+  const int qloc = threadIdx.x;
+  if (qloc >= wk.qn) return;
+  const int64_t qrow = wk.q0 + qloc;
+  double q[16], qn2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    q[c] = (double)qf[qrow * 16 + c];
+    qn2 = fma(q[c], q[c], qn2);
+  }
+  double bd[KNN_MAXK];
+  int32_t bi[KNN_MAXK];
+#pragma unroll
+  for (int j = 0; j < KNN_MAXK; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+  const int32_t* ci = cand_i + (wk.o0 + qloc) * 2 * KNF_KK;
+  int n_cand = 0;
+  for (int c = 0; c < 2 * KNF_KK; ++c) {
+    const int32_t row = ci[c];
+    if (row == 0x7fffffff) continue;
+    ++n_cand;
+    const float* tp = tf + (wk.t0 + row) * 16;
+    double d = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double diff = q[e] - (double)tp[e];
+      d = fma(diff, diff, d);
+    }
+    double cd = d;
+    int32_t cr = row;
+    bool carry = false;
+#pragma unroll
+    for (int s2 = 0; s2 < KNN_MAXK; ++s2) {
+      if (carry || cd < bd[s2] || (cd == bd[s2] && cr < bi[s2])) {
+        carry = true;
+        const double td = bd[s2];
+        const int32_t ti = bi[s2];
+        bd[s2] = cd;
+        bi[s2] = cr;
+        cd = td;
+        cr = ti;
+      }
+    }
+  }
+  const int64_t orow = wk.o0 + qloc;
+  double dk = INFINITY;  // exact k-th distance
+  for (int j = 0; j < k; ++j) {
+    double dj = INFINITY;
+    int32_t ij = 0x7fffffff;
+#pragma unroll
+    for (int s2 = 0; s2 < KNN_MAXK; ++s2)
+      if (s2 == j) {
+        dj = bd[s2];
+        ij = bi[s2];
+      }
+    const bool have = ij != 0x7fffffff;
+    out_idx[orow * k + j] = have ? ij : -1;
+    if (out_dist) out_dist[orow * k + j] = have ? sqrt(dj) : INFINITY;
+    dk = dj;
+  }
+  // Verification.  Targets that were dropped have approximate value >= tau, i.e. exact
+  // |t|^2 - 2 q.t >= tau - eps with eps covering: 48 f32 accumulation steps and the dropped lo*lo
+  // products relative to sum |terms| <= |q|^2 + |t|^2, the hi+lo split residuals, the f32 rounding of
+  // |t|^2 -- together < 2^-17 (|q|^2 + |t|^2_max); charged 2^-15.  If the shortlists were never filled
+  // (tau = +inf) every target of the query's part is a candidate and nothing was dropped.
+  const float tau = cand_tau[orow];
+  const double t2max = (double)__uint_as_float(seg_t2max_bits[wk.pad]);
+  const double eps = 0x1.0p-15 * (qn2 + t2max);
+  bool ok = true;
+  if (tau < INFINITY) {
+    // need: exact k-th (as |t|^2 - 2 q.t = d - |q|^2) strictly below every dropped target's exact value;
+    // equality would need the (distance, row) tie rule, which the shortlist does not know
+    ok = n_cand >= k && (dk - qn2) < (double)tau - eps;
+  }
+  if (!(qn2 < 1.0e8) || !(t2max < 1.0e8)) ok = false;  // outside the f16 range: not trusted at all
+  qflag[orow] = ok ? 0 : 1;
+  if (!ok) atomicOr(&tile_flag[blockIdx.x], 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -938,7 +1325,26 @@ static int upload(PoolBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
 
 using namespace cs;
 
+// {queries answered by the f16 shortlist path, of those recomputed exhaustively}; counted only while
+// CS_KNN_STATS=1 (the count costs a synchronisation)
+static std::atomic<unsigned long long> g_knn_stats[2];
+
+__global__ void k_count_flags(const int32_t* __restrict__ flag, int64_t n, unsigned long long* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  unsigned long long v = (i < n && flag[i]) ? 1ULL : 0ULL;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
 extern "C" {
+
+void cs_knn_shortlist_stats(uint64_t out[2], int reset) {
+  for (int i = 0; i < 2; ++i) {
+    if (out) out[i] = g_knn_stats[i].load();
+    if (reset) g_knn_stats[i].store(0);
+  }
+}
 
 int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
                 const int64_t* h_toff, const int32_t* h_qseg, const int32_t* h_tseg, int n_prob,
@@ -956,10 +1362,12 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
-  // 16-d features with k <= KNM_KK - 2 go through the f64 matrix pipe (shortlist + canonical rescore);
-  // CS_KNN_MFMA=0 forces the all-VALU exact kernel
+  // 16-d features with k <= 6: f16 matrix-core shortlist + canonical rescore + verification (default);
+  // CS_KNN_MFMA=64 selects the f64 matrix-pipe shortlist, CS_KNN_MFMA=0 the all-VALU exhaustive kernel
   const char* env = getenv("CS_KNN_MFMA");
-  const bool mfma = dim == 16 && k <= KNM_KK - 2 && !(env && env[0] == '0');
+  const bool small = dim == 16 && k <= KNM_KK - 2;
+  const bool f16path = small && !(env && (env[0] == '0' || env[0] == '6'));
+  const bool mfma = small && env && env[0] == '6';
   const int qtile = mfma ? KNM_QT : 256;
   std::vector<KnnWork> work;
   int64_t out_row = 0;
@@ -992,6 +1400,79 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   if (rc) return rc;
   double knn_flop = 0.0;
   for (const KnnWork& w : work) knn_flop += 3.0 * (double)w.qn * (double)w.tn * (double)dim;
+  if (f16path) {
+    const int64_t nq_rows = h_qoff[nqseg], nt_rows = h_toff[ntseg];
+    CS_REQUIRE(nt_rows < (1LL << 31) && ntseg < (1 << 27), CS_ERR_UNSUPPORTED,
+               "cs_knn_feat: too many target rows / segments");
+    PoolBuf<_Float16> qrows((size_t)(nq_rows ? nq_rows : 1) * 48);
+    PoolBuf<_Float16> img((size_t)(nt_rows + KNF_ROWS) * KNF_PITCH);  // + one stage of slack for the last copy
+    PoolBuf<float> tn32((size_t)(nt_rows ? nt_rows : 1)), tau((size_t)(out_row ? out_row : 1));
+    PoolBuf<int32_t> ti32((size_t)(nt_rows ? nt_rows : 1)), cand((size_t)(out_row ? out_row : 1) * 2 * KNF_KK);
+    PoolBuf<int32_t> qflag((size_t)(out_row ? out_row : 1)), tile_flag(work.size());
+    PoolBuf<unsigned> t2max((size_t)ntseg);
+    PoolBuf<int32_t> torder, rows_in, lab_start;
+    PoolBuf<uint32_t> keys, keys_sorted;
+    PoolBuf<int64_t> dtoff;
+    PoolBuf<char> tmp;
+    CS_REQUIRE(qrows.p && img.p && tn32.p && tau.p && ti32.p && cand.p && qflag.p && tile_flag.p && t2max.p,
+               CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+    std::vector<int64_t> toff(h_toff, h_toff + ntseg + 1);
+    rc = upload(dtoff, toff, s);
+    if (rc) return rc;
+    if (d_tlabel && nt_rows) {
+      // label order of every target segment (stable: equal labels keep their row order)
+      CS_REQUIRE(torder.alloc((size_t)nt_rows) && keys.alloc((size_t)nt_rows) &&
+                     keys_sorted.alloc((size_t)nt_rows) && rows_in.alloc((size_t)nt_rows) &&
+                     lab_start.alloc((size_t)ntseg * 10),
+                 CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      hipLaunchKernelGGL(k_seg_keys, dim3(16, (unsigned)ntseg), dim3(256), 0, s, dtoff.p, ntseg, d_tlabel,
+                         keys.p, rows_in.p);
+      int end_bit = 4;
+      while ((1LL << end_bit) < (int64_t)ntseg * 16) ++end_bit;
+      size_t tmp_bytes = 0;
+      CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.p, keys_sorted.p, rows_in.p,
+                                                      torder.p, (int)nt_rows, 0, end_bit, s));
+      CS_REQUIRE(tmp.alloc(tmp_bytes ? tmp_bytes : 1), CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.p, keys_sorted.p, rows_in.p,
+                                                      torder.p, (int)nt_rows, 0, end_bit, s));
+      hipLaunchKernelGGL(k_label_starts, dim3((unsigned)ceil_div((int64_t)ntseg * 10, 256)), dim3(256), 0, s,
+                         dtoff.p, ntseg, keys_sorted.p, lab_start.p);
+    }
+    CS_HIP_CHECK(hipMemsetAsync(t2max.p, 0, sizeof(unsigned) * ntseg, s));
+    CS_HIP_CHECK(hipMemsetAsync(tile_flag.p, 0, sizeof(int32_t) * work.size(), s));
+    if (nt_rows)
+      hipLaunchKernelGGL(k_knf_pack_targets, dim3(16, (unsigned)ntseg), dim3(256), 0, s, d_tf, dtoff.p, ntseg,
+                         (d_tlabel && nt_rows) ? torder.p : (const int32_t*)nullptr, img.p, tn32.p, ti32.p, t2max.p);
+    if (nq_rows)
+      hipLaunchKernelGGL(k_knf_pack_queries, dim3((unsigned)ceil_div(nq_rows, 256)), dim3(256), 0, s, d_qf,
+                         nq_rows, qrows.p);
+    {
+      ProfScope prof("knn", s, knn_flop);
+      hipLaunchKernelGGL(k_knn_f16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, qrows.p, img.p,
+                         tn32.p, ti32.p, d_qlabel, d_perm, (d_tlabel && nt_rows) ? lab_start.p : (const int32_t*)nullptr,
+                         cand.p, tau.p);
+      hipLaunchKernelGGL(k_knn_rescore_f16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_qf, d_tf,
+                         cand.p, tau.p, t2max.p, k, d_idx, d_dist, qflag.p, tile_flag.p);
+      // exhaustive recomputation of the queries whose shortlist could not be verified (normally none)
+      hipLaunchKernelGGL((k_knn_feat<16>), dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
+                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist, tile_flag.p, qflag.p);
+      CS_LAUNCH_CHECK();
+    }
+    const char* env_st = getenv("CS_KNN_STATS");
+    if (env_st && env_st[0] == '1' && out_row > 0) {
+      PoolBuf<unsigned long long> cnt(1);
+      CS_REQUIRE(cnt.p, CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
+      CS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_count_flags, dim3((unsigned)ceil_div(out_row, 256)), dim3(256), 0, s, qflag.p, out_row,
+                         cnt.p);
+      unsigned long long h = 0;
+      CS_HIP_CHECK(hipMemcpyAsync(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, s));
+      CS_HIP_CHECK(hipStreamSynchronize(s));
+      g_knn_stats[0] += (unsigned long long)out_row;
+      g_knn_stats[1] += h;
+    }
+    return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
+  }
   if (mfma) {
     const int64_t nq_rows = h_qoff[nqseg], nt_rows = h_toff[ntseg];
     CS_REQUIRE(nt_rows < (1LL << 31) && ntseg < (1 << 27), CS_ERR_UNSUPPORTED,
@@ -1046,15 +1527,16 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   {
     ProfScope prof("knn", s, knn_flop);
     dim3 grid((unsigned)work.size());
+    const int32_t* none = nullptr;
     if (dim == 16)
       hipLaunchKernelGGL((k_knn_feat<16>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
-                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist);
+                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist, none, none);
     else if (dim == 32)
       hipLaunchKernelGGL((k_knn_feat<32>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k,
-                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist);
+                         d_qlabel, d_tlabel, d_perm, d_idx, d_dist, none, none);
     else
       hipLaunchKernelGGL((k_knn_feat<3>), grid, dim3(256), 0, s, dwork.p, d_qf, d_tf, k, d_qlabel,
-                         d_tlabel, d_perm, d_idx, d_dist);
+                         d_tlabel, d_perm, d_idx, d_dist, none, none);
     CS_LAUNCH_CHECK();
   }
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order

@@ -158,6 +158,13 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
                 int dim, int k, const int32_t* d_qlabel, const int32_t* d_tlabel,
                 const int32_t* d_perm, int32_t* d_idx, double* d_dist, void* stream);
 
+/* Diagnostics of cs_knn_feat's default path for 16-d features (f16 matrix-core shortlist, canonical f64
+ * re-evaluation, verification, exhaustive recomputation of what could not be verified): out =
+ * {queries answered, of those recomputed exhaustively}, counted only while the environment variable
+ * CS_KNN_STATS=1.  CS_KNN_MFMA=64 selects the f64 matrix-pipe shortlist, CS_KNN_MFMA=0 the exhaustive
+ * all-VALU kernel; all three return the same indices and distances. */
+void cs_knn_shortlist_stats(uint64_t out[2], int reset);
+
 /* ------------------------------------------------------------------------------------------
  * One-directional Chamfer.  Replaces apply_transform + chamfer_kdtree_1direction
  * (utils/preprocess.py:39-48,67-70): problem p transforms the source segment with the f32

@@ -47,10 +47,11 @@ def test_l2_topk_bit_exact_vs_oracle(gpu, oracle_native, nq, nx, d, k):
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
 
 
-@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("mfma", ["1", "64", "0"])
 def test_knn_feat_bit_exact(gpu, oracle_native, monkeypatch, mfma):
-    """Both code paths: the f64 matrix-pipe shortlist + canonical rescore (default for 16-d features) and
-    the all-VALU exact kernel (CS_KNN_MFMA=0) return the oracle's indices and distances."""
+    """All three code paths return the oracle's indices and distances: the f16 matrix-core shortlist with
+    canonical rescore + verification (default for 16-d features), the f64 matrix-pipe shortlist
+    (CS_KNN_MFMA=64) and the exhaustive all-VALU kernel (CS_KNN_MFMA=0)."""
     from corsair_amd import backend as B
 
     monkeypatch.setenv("CS_KNN_MFMA", mfma)

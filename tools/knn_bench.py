@@ -19,3 +19,11 @@ for rep in range(3):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
     pairs = sum(a * a for a in n)
     print("knn %.3f ms per call, %.2f Gpairs/s, checksum %d" % (dt * 1e3, pairs / dt / 1e9, int(idx.sum())))
+import ctypes
+from corsair_amd import _lib
+os.environ["CS_KNN_STATS"] = "1"
+st = (ctypes.c_uint64 * 2)()
+_lib.load().cs_knn_shortlist_stats(st, 1)
+B.knn_feat(Q, off, T, off, 5)
+_lib.load().cs_knn_shortlist_stats(st, 0)
+print("shortlist stats [queries, recomputed exhaustively]:", [int(v) for v in st])
