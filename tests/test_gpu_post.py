@@ -93,6 +93,33 @@ def test_knn_feat_bit_exact(gpu, oracle_native, monkeypatch, mfma):
         row += a
 
 
+def test_knn_f16_shortlist_falls_back_on_ties(gpu, oracle_native, monkeypatch):
+    """40 identical target rows tie for every query's nearest neighbours: the shortlist cannot be verified
+    (the dropped copies are as close as the kept ones), the flagged queries are recomputed exhaustively and
+    the (distance, smaller row) rule of the oracle holds."""
+    import ctypes
+
+    from corsair_amd import _lib, backend as B
+
+    rng = np.random.default_rng(12)
+    nq, nt = 700, 3000
+    qf = _feat(rng, nq)
+    tf = _feat(rng, nt)
+    dup = rng.choice(nt, 40, replace=False)
+    tf[dup] = qf[3] * np.float32(0.999)          # 40 copies of a vector next to query 3
+    monkeypatch.setenv("CS_KNN_STATS", "1")
+    st = (ctypes.c_uint64 * 2)()
+    _lib.load().cs_knn_shortlist_stats(st, 1)
+    idx, dist = B.knn_feat(torch.from_numpy(qf).to(gpu), [0, nq], torch.from_numpy(tf).to(gpu), [0, nt], 5,
+                           return_distance=True)
+    _lib.load().cs_knn_shortlist_stats(st, 0)
+    wi, wd = oracle_native.knn(qf, tf, 5, return_distance=True)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(dist.cpu().numpy(), wd)
+    assert np.array_equal(wi[3], np.sort(dup)[:5])           # the tie rule is what decides query 3
+    assert int(st[0]) == nq and 1 <= int(st[1]) < nq // 4    # some, not most, went through the fallback
+
+
 @pytest.mark.parametrize("mfma", ["1", "0"])
 def test_chamfer_matches_oracle(gpu, oracle_native, monkeypatch, mfma):
     """f64 matrix-pipe arg-min + canonical re-evaluation (default) and the exhaustive VALU chain."""
