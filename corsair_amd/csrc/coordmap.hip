@@ -643,6 +643,8 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
   // LDS path: per-sample hash tables (see k_build_nbr_lds); otherwise the global table
   bool used_lds = false, need_global = false;
   PoolBuf<int> fb;
+  unsigned long long* lds_cnt = nullptr;  // counter / flags written by the LDS path
+  int* lds_fb = nullptr;
   if (e == hipSuccess && total > 0 && km->kvol == 27 && getenv("CS_KMAP_GLOBAL") == nullptr) {
     cs_coordmap* in_m = const_cast<cs_coordmap*>(in);
     cs_coordmap* out_m = const_cast<cs_coordmap*>(out);
@@ -650,26 +652,31 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
         in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch &&
         true) {
       const int nb = in_m->n_batch;
-      fb.alloc(nb);
-      std::vector<int> h_fb(nb, 0);
+      // pair counter and per-sample fallback flags in one block: one memset, one copy back
+      fb.alloc(2 + nb);
+      std::vector<int> h_st(2 + nb, 0);
       if (fb.p) {
+        unsigned long long* const cnt_p = reinterpret_cast<unsigned long long*>(fb.p);
+        int* const fb_p = fb.p + 2;
         int slices = 512 / (nb > 0 ? nb : 1);
         if (slices < 1) slices = 1;
         if (slices > 8) slices = 8;
-        e = hipMemsetAsync(fb.p, 0, sizeof(int) * nb, s);
+        e = hipMemsetAsync(fb.p, 0, sizeof(int) * (2 + nb), s);
         if (e == hipSuccess) {
           hipLaunchKernelGGL(k_build_nbr_lds, dim3((unsigned)slices, (unsigned)nb), dim3(1024), 0, s,
                              in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                             in->tensor_stride, step, sign, km->d_nbr, cnt.p, fb.p);
+                             in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
           e = hipGetLastError();
         }
         if (e == hipSuccess)
-          e = hipMemcpyAsync(h_fb.data(), fb.p, sizeof(int) * nb, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
+          e = hipMemcpyAsync(h_st.data(), fb.p, sizeof(int) * (2 + nb), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e == hipSuccess) {
           used_lds = true;
-          for (int b = 0; b < nb; ++b) need_global = need_global || h_fb[b] != 0;
+          memcpy(&h_cnt, h_st.data(), sizeof(h_cnt));
+          for (int b = 0; b < nb; ++b) need_global = need_global || h_st[2 + b] != 0;
+          lds_cnt = cnt_p;
+          lds_fb = fb_p;
         }
       }
     }
@@ -677,9 +684,11 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
   if (e == hipSuccess && total > 0 && (!used_lds || need_global)) {
     hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        out->d_coords, km->n_out, km->kvol, step, sign, in->d_keys, in->d_vals,
-                       in->capacity - 1, km->d_nbr, cnt.p, used_lds ? fb.p : (const int*)nullptr);
+                       in->capacity - 1, km->d_nbr, used_lds ? lds_cnt : cnt.p,
+                       used_lds ? lds_fb : (const int*)nullptr);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&h_cnt, used_lds ? lds_cnt : cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
   }
   if (e != hipSuccess) {
