@@ -114,7 +114,7 @@ def main():
 
     def step(b):
         qs = pipe.embed_batch(q_dev[b], q_off[b])
-        top = pipe.retrieve(qs.desc, catalog.desc, 1)[:, 0].cpu().numpy()
+        top = _lib.to_host(pipe.retrieve(qs.desc, catalog.desc, 1)[:, 0])[0]
         cads = catalog.gather(top)
         ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
         # force_gate: with random-init weights the part-cut acceptance gate (tuned to trained
@@ -123,8 +123,8 @@ def main():
         # the timed region.  The bench accepts the best-balanced anchor so every query runs
         # 1 + K (+4) RANSACs like the reference workload.  Parity tests use the real gate.
         res = pipe.register(qs, cads, sym[top], anchor_ids=ids, force_gate=True)
-        results.append((b, top, res.T_best.cpu().numpy(), res.T_ransac.cpu().numpy(),
-                        res.cd_best.cpu().numpy(), res.ok, res.iters.cpu().numpy(), res.n_problems))
+        Tb, Tr, cdb, its = _lib.to_host(res.T_best, res.T_ransac, res.cd_best, res.iters)
+        results.append((b, top, Tb, Tr, cdb, res.ok, its, res.n_problems))
 
     def barrier():
         if dist is not None:

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import backend as B
+from ._lib import to_host
 
 ANCHOR_KEY = 0x5A11C0DE
 
@@ -169,7 +170,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             off_all = off0 + [off0[-1] + o for o in off1[1:]]
             c, cnt, mcd, mer = B.symcut_fit(torch.cat([baseF, posF]), torch.cat([xyz0, xyz1]), off_all, a_all,
                                             Ks + Ks, 50, 10, 300, 0)
-            c, cnt, mcd, mer = c.cpu().numpy(), cnt.cpu().numpy(), mcd.cpu().numpy(), mer.cpu().numpy()
+            c, cnt, mcd, mer = to_host(c, cnt, mcd, mer)
             c0, cnt0, mcd0, mer0 = c[:P], cnt[:P], mcd[:P], mer[:P]
             c1, cnt1, mcd1, mer1 = c[P:], cnt[P:], mcd[P:], mer[P:]
             g0, ok0 = gate_and_order_batch(c0, cnt0, mcd0, mer0, n0, Ks, cand, force_gate)
@@ -208,7 +209,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             neg = torch.cumsum((nn_cfg < 0).any(dim=1).to(torch.int32), 0)
             neg = torch.cat([neg.new_zeros(1), neg])
             ends = torch.from_numpy(row_start).to(dev)
-            bad = (neg[ends[1:]] - neg[ends[:-1]]).cpu().numpy() > 0
+            bad = to_host(neg[ends[1:]] - neg[ends[:-1]])[0] > 0
             keep = [j for j in range(len(cfg_pair)) if not bad[j]]
             if keep:
                 L = torch.from_numpy(lens[keep]).to(dev)
@@ -240,7 +241,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
     cd = B.chamfer_1dir(xyz0, off0, xyz1, off1, prob_pair, prob_pair, T)
 
     # ---- 6. best hypothesis per pair: first minimum, vanilla first (utils/symmetry.py:322-324) ----
-    cd_h = cd.cpu().numpy()
+    cd_h = to_host(cd)[0]
     pair_h = np.asarray(prob_pair)
     best = np.arange(P)
     for j in range(P, len(pair_h)):
