@@ -34,7 +34,10 @@ void set_error(const char* fmt, ...);
 // Size-class caching device allocator for library-owned scratch and map storage.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
-void pool_use_stream(hipStream_t s);  // see runtime.hip: scratch is cached per (thread, stream)
+void pool_use_stream(hipStream_t s);
+// device -> host through the thread's page-locked staging buffer (runtime.hip); sync hands the bytes out
+hipError_t download_async(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s);
+hipError_t download_sync(hipStream_t s);  // see runtime.hip: scratch is cached per (thread, stream)
 
 template <typename T>
 struct PoolBuf {

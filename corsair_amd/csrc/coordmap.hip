@@ -270,9 +270,8 @@ static int ensure_segments(cs_coordmap* m, hipStream_t s) {
   m->seg_state = -1;  // unavailable unless everything below succeeds
   if (m->n == 0) return CS_OK;
   int32_t last_b = -1;
-  CS_HIP_CHECK(hipMemcpyAsync(&last_b, m->d_coords + 4 * (m->n - 1), sizeof(int32_t),
-                              hipMemcpyDeviceToHost, s));
-  CS_HIP_CHECK(hipStreamSynchronize(s));
+  CS_HIP_CHECK(download_async(&last_b, m->d_coords + 4 * (m->n - 1), sizeof(int32_t), s));
+  CS_HIP_CHECK(download_sync(s));
   if (last_b < 0 || last_b >= 65536) return CS_OK;
   const int nb = last_b + 1;
   int32_t* seg = (int32_t*)pool_alloc((size_t)(nb + 1) * sizeof(int32_t));
@@ -288,8 +287,8 @@ static int ensure_segments(cs_coordmap* m, hipStream_t s) {
                      m->n, nb, seg, flags.p);
   hipLaunchKernelGGL(k_segment_max, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, s, seg, nb,
                      flags.p);
-  CS_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s));
-  CS_HIP_CHECK(hipStreamSynchronize(s));
+  CS_HIP_CHECK(download_async(h_flags, flags.p, sizeof(h_flags), s));
+  CS_HIP_CHECK(download_sync(s));
   if (h_flags[0]) {
     pool_free(seg);
     return CS_OK;  // not grouped by sample: global path
@@ -478,8 +477,8 @@ int cs_coordmap_create(const int32_t* d_coords, int64_t n, int tensor_stride, vo
       e = hipGetLastError();
     }
     if (e == hipSuccess)
-      e = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+      e = download_async(h_status, status.p, sizeof(h_status), s);
+    if (e == hipSuccess) e = download_sync(s);
     if (e != hipSuccess) {
       cs_coordmap_free(m);
       set_error("cs_coordmap_create: %s", hipGetErrorString(e));
@@ -547,12 +546,12 @@ int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coord
       cs_coordmap_free(m);
       return rc;
     }
-    e = hipMemcpyAsync(&h_last[0], pos.p + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    e = download_async(&h_last[0], pos.p + (n - 1), sizeof(int32_t), s);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(&h_last[1], flag.p + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+      e = download_async(&h_last[1], flag.p + (n - 1), sizeof(int32_t), s);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(h_status, status.p, sizeof(h_status), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+      e = download_async(h_status, status.p, sizeof(h_status), s);
+    if (e == hipSuccess) e = download_sync(s);
     if (e != hipSuccess) {
       cs_coordmap_free(m);
       set_error("cs_coordmap_stride: %s", hipGetErrorString(e));
@@ -577,7 +576,7 @@ int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coord
                        m->capacity - 1, m->d_coords);
     hipError_t e = hipGetLastError();
     // flag/pos go back to the pool when this function returns; make sure the kernel is done
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = download_sync(s);
     if (e != hipSuccess) {
       cs_coordmap_free(m);
       set_error("cs_coordmap_stride: %s", hipGetErrorString(e));
@@ -669,8 +668,8 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
           e = hipGetLastError();
         }
         if (e == hipSuccess)
-          e = hipMemcpyAsync(h_st.data(), fb.p, sizeof(int) * (2 + nb), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+          e = download_async(h_st.data(), fb.p, sizeof(int) * (2 + nb), s);
+        if (e == hipSuccess) e = download_sync(s);
         if (e == hipSuccess) {
           used_lds = true;
           memcpy(&h_cnt, h_st.data(), sizeof(h_cnt));
@@ -688,8 +687,8 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
                        used_lds ? lds_fb : (const int*)nullptr);
     e = hipGetLastError();
     if (e == hipSuccess)
-      e = hipMemcpyAsync(&h_cnt, used_lds ? lds_cnt : cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+      e = download_async(&h_cnt, used_lds ? lds_cnt : cnt.p, sizeof(h_cnt), s);
+    if (e == hipSuccess) e = download_sync(s);
   }
   if (e != hipSuccess) {
     cs_kernelmap_free(km);
@@ -752,7 +751,7 @@ int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in,
   hipLaunchKernelGGL(k_export_emit, dim3(g), dim3(256), 0, s, km->d_nbr, km->n_out, km->kvol,
                      flag.p, pos.p, capacity, d_k, d_in, d_out);
   CS_LAUNCH_CHECK();
-  CS_HIP_CHECK(hipStreamSynchronize(s));
+  CS_HIP_CHECK(download_sync(s));
   return km->num_pairs;
 }
 

@@ -38,7 +38,9 @@ static thread_local bool t_stream_set = false;
 
 // Entry points that free scratch without waiting for their kernels call this first: the cache is only
 // stream-ordered, so a thread that switches streams drains the old one before blocks change hands.
+static void download_reset();
 void pool_use_stream(hipStream_t s) {
+  download_reset();  // entry of a public call: downloads left pending by a failed call are dropped
   if (t_stream_set && t_stream != s) (void)hipStreamSynchronize(t_stream);
   t_stream = s;
   t_stream_set = true;
@@ -97,6 +99,65 @@ void pool_free(void* p) {
     g_live.erase(it);
   }
   t_cache.free_[c].push_back(p);
+}
+
+// ---- small device -> host downloads ----------------------------------------------------------
+// hipMemcpyAsync into pageable host memory makes the runtime block on the stream first (slow wake-up,
+// tens to hundreds of microseconds of GPU idle after a long kernel) and stage the bytes afterwards.
+// The sizes, counters and flags the host needs go through a page-locked buffer of the calling thread
+// instead: download_async enqueues, download_sync waits once and hands the bytes out.
+namespace {
+struct Downloads {
+  char* pinned = nullptr;
+  size_t cap = 0, used = 0;
+  struct Item {
+    void* dst;
+    size_t off, n;
+  };
+  std::vector<Item> items;
+  ~Downloads() {
+    if (pinned) (void)hipHostFree(pinned);
+  }
+};
+thread_local Downloads t_dl;
+}  // namespace
+
+static void download_reset() {
+  t_dl.items.clear();
+  t_dl.used = 0;
+}
+
+hipError_t download_async(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s) {
+  const size_t need = t_dl.used + ((bytes + 15) / 16) * 16;
+  if (need > t_dl.cap) {
+    if (!t_dl.items.empty()) {  // cannot move a buffer with copies in flight: fall back to a plain copy
+      hipError_t e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s);
+      return e;
+    }
+    size_t cap = t_dl.cap ? t_dl.cap : 4096;
+    while (cap < need) cap *= 2;
+    if (t_dl.pinned) (void)hipHostFree(t_dl.pinned);
+    t_dl.pinned = nullptr;
+    t_dl.cap = 0;
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s);
+    t_dl.pinned = static_cast<char*>(q);
+    t_dl.cap = cap;
+  }
+  hipError_t e = hipMemcpyAsync(t_dl.pinned + t_dl.used, dev_src, bytes, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  t_dl.items.push_back({host_dst, t_dl.used, bytes});
+  t_dl.used = need;
+  return hipSuccess;
+}
+
+hipError_t download_sync(hipStream_t s) {
+  hipError_t e = hipStreamSynchronize(s);
+  for (const auto& it : t_dl.items) memcpy(it.dst, t_dl.pinned + it.off, it.n);
+  t_dl.items.clear();
+  t_dl.used = 0;
+  return e;
 }
 
 // ---- profiling -----------------------------------------------------------------------------

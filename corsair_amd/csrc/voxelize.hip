@@ -158,10 +158,9 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
                      d_off.p, n_seg, n, pos.p, flag.p, d_out_off.p);
   CS_LAUNCH_CHECK();
   int h_status = 0;
-  CS_HIP_CHECK(hipMemcpyAsync(&h_status, status.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  CS_HIP_CHECK(hipMemcpyAsync(h_out_offsets, d_out_off.p, sizeof(int64_t) * (n_seg + 1),
-                              hipMemcpyDeviceToHost, s));
-  CS_HIP_CHECK(hipStreamSynchronize(s));
+  CS_HIP_CHECK(download_async(&h_status, status.p, sizeof(int), s));
+  CS_HIP_CHECK(download_async(h_out_offsets, d_out_off.p, sizeof(int64_t) * (n_seg + 1), s));
+  CS_HIP_CHECK(download_sync(s));
   CS_REQUIRE(!h_status, CS_ERR_RANGE,
              "cs_voxelize: voxel index out of the supported range (|index| < 32768)");
   return CS_OK;
