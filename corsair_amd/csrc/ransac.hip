@@ -1234,8 +1234,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   std::vector<int32_t> h_surv(n_prob), h_xcd;
   int pslots = 1;
-  PoolBuf<int32_t> xcd_prob((size_t)8 * n_prob);
-  CS_REQUIRE(xcd_prob.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
+  // two copies of the placement table, used alternately: the hypotheses of the next chunk are
+  // enqueued with this round's table while the next round uploads its own
+  PoolBuf<int32_t> xcd_buf((size_t)16 * n_prob);
+  CS_REQUIRE(xcd_buf.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
+  int32_t* xcd_prob = xcd_buf.p;
+  int round = 0;
   CS_HIP_CHECK(hipMemcpyAsync(d_probs, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
@@ -1279,7 +1283,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     ProfScope prof("ransac_hyp", s);
     const int htiles = (count + 255) / 256;
     hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
-                       pair32.p, first, count, bmax, ransac_n, seed, xcd_prob.p, pslots, htiles, hyp.p);
+                       pair32.p, first, count, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp.p);
   };
   int it0 = 0;
   while (it0 < max_iter) {
@@ -1318,7 +1322,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       for (int x = 0; x < 8; ++x)
         for (size_t i = 0; i < lists[x].size(); ++i) h_xcd[(size_t)x * pslots + i] = lists[x][i];
     }
-    CS_HIP_CHECK(hipMemcpyAsync(xcd_prob.p, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
+    xcd_prob = xcd_buf.p + (size_t)(round++ & 1) * 8 * n_prob;
+    CS_HIP_CHECK(hipMemcpyAsync(xcd_prob, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
                                 hipMemcpyHostToDevice, s));
     if (!hyp_ready) launch_hyp(it0, b);
     hyp_ready = false;
@@ -1361,7 +1366,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         ProfScope prof("ransac_pre", s, 94.0 * eval_pairs);
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
         hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, d_probs, off16.p, B16.p,
-                           A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob.p, pslots, ptiles, cnt_up.p,
+                           A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob, pslots, ptiles, cnt_up.p,
                            (trace_it0 == it0) ? trace.p : nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
