@@ -4,24 +4,33 @@
 // (utils/eval_pose.py:82-100 of the reference; ransac_n = 10, 100 000 iterations, confidence 0.999).
 // Semantics: Open3D's loop as executed by ONE thread (iteration order = index order), with the
 // global Mersenne twister replaced by a counter-based generator so that iteration i of every
-// problem is reproducible anywhere.  Iterations are processed in growing chunks; within a chunk
-//   k_ransac_hyp    one lane per hypothesis: sample ransac_n pairs, closed-form rigid fit
-//                   (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f32
-//   k_ransac_count  the hot kernel.  A wave owns 32 hypotheses; the residual d = R s + t - q of a
-//                   32-correspondence x 32-hypothesis tile is TWO v_mfma_f32_32x32x2_f32 per
-//                   coordinate (K = [sx, sy | sz, 1] against [r0, r1 | r2, t]) whose accumulator
-//                   INPUT is -q read straight from LDS: the matrix pipe does the 21 transform and
-//                   residual flops of every (hypothesis, pair), the VALU only the squared norm,
-//                   compare and count (5 instructions per pair) and runs concurrently.
-//                   f32 MFMA is an ordered fma chain, so the inlier test is bit-identical to the
-//                   scalar oracle:  d = fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))).
-//                   Correspondences are staged per 256 through LDS as structure-of-arrays.
-//   k_ransac_scan1  one wave per problem replays the chunk in iteration order (prefix max of the
-//                   inlier counts -> early-exit bound est_k -> stop position) and lists the
-//                   hypotheses that tie for the best count
-//   k_ransac_err    fixed-point squared error (exact integer sums) of those few candidates only
-//   k_ransac_scan2  best = max count, then min error, then first -- the final state of the
-//                   sequential rule "better = more inliers, or equal inliers and smaller rmse"
+// problem is reproducible anywhere.  Iterations are processed in growing chunks (256, 256, 512, ...,
+// 16 384); within a chunk
+//   k_ransac_hyp        one lane per hypothesis: sample ransac_n pairs (packed 32-B rows), closed-form
+//                       rigid fit (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f32
+//   k_ransac_prefilter  (from iteration 512 on) an UPPER bound of every hypothesis' inlier count on the
+//                       f16 matrix cores; hypotheses whose bound is below the carried best cannot
+//                       matter and get count 0.  ~0.02 % survive.  See the block comment above the
+//                       kernel and DESIGN.md ("RANSAC prefilter") for the bound.
+//   k_ransac_count      the exact count: a wave owns 32 hypotheses; the residual d = R s + t - q of a
+//                       32-correspondence x 32-hypothesis tile is TWO v_mfma_f32_32x32x2_f32 per
+//                       coordinate (K = [sx, sy | sz, 1] against [r0, r1 | r2, t]) whose accumulator
+//                       INPUT is -q read straight from LDS; the VALU does the squared norm, compare
+//                       and count.  f32 MFMA is an ordered fma chain, so the inlier test is
+//                       bit-identical to the scalar oracle:
+//                       d = fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))).
+//                       Used for all hypotheses of the first 512 iterations and (LIST) for long
+//                       survivor lists; k_ransac_count_few handles the usual handful of survivors
+//                       (canonical chain on the VALU, count and fixed-point error in one pass).
+//   k_ransac_scan1      one wave per problem replays the chunk in iteration order (prefix max of the
+//                       inlier counts -> early-exit bound est_k -> stop position) and lists the
+//                       hypotheses that tie for the best count
+//   k_ransac_err        fixed-point squared error (exact integer sums) of those few candidates (only
+//                       when k_ransac_count_few has not produced it already)
+//   k_ransac_scan2      best = max count, then min error, then first -- the final state of the
+//                       sequential rule "better = more inliers, or equal inliers and smaller rmse"
+// The host loop synchronises once per chunk (one pinned copy of the per-problem state); the next
+// chunk's hypotheses are already enqueued at that point.
 // Inlier counts and fixed-point errors are integers, so any split of the correspondence range across
 // workgroups gives identical sums.
 #include <math.h>
