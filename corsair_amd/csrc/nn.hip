@@ -4,10 +4,16 @@
 //   cs_knn_feat     <- KDTree(feat1).query(feat0, k)     (utils/find_nn.py:43-49, utils/eval_pose.py:48-79,
 //                                                         utils/symmetry.py:145-179)
 //   cs_chamfer_1dir <- apply_transform + KDTree 1-NN     (utils/preprocess.py:39-48,67-70)
-// Distances are evaluated as one fma chain over the feature dimension in ascending order; ties go
-// to the smaller index.  These kernels are VALU(f64)-bound with every operand staged through LDS
-// (targets) or held in registers (queries); HBM traffic is the algorithmic minimum (each row read
-// once per query tile).
+// The canonical distance is one f64 fma chain over the feature dimension in ascending order; ties go
+// to the smaller index.  Every returned index / distance is that of the canonical chain.  The fast
+// paths only decide WHICH rows get the canonical evaluation:
+//   * 16-d k-NN: shortlist by |t|^2 - 2 q.t on the f16 matrix cores (k_knn_f16), canonical rescore,
+//     verification of the shortlist, exhaustive recomputation of unverified queries (k_knn_feat);
+//   * Chamfer / Hausdorff: arg-min of |t|^2 - 2 p.t on the f64 matrix pipe, canonical chain on the
+//     candidates (k_chamfer_mfma);
+//   * descriptor top-k at stress sizes: f64 matrix-pipe shortlist + canonical rescore (k_topk_mfma).
+// The exhaustive VALU kernels (k_knn_feat, k_chamfer, k_dist_matrix + k_row_topk) remain selectable
+// by environment variable and are what the fast paths are tested against.
 #include <stdlib.h>
 
 #include <hipcub/hipcub.hpp>
