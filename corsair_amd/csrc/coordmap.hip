@@ -198,12 +198,29 @@ __global__ __launch_bounds__(1024) void k_build_nbr_lds(
   }
   for (int i = tid; i < LDS_SLOTS; i += 1024) keys[i] = LDS_EMPTY;
   __syncthreads();
-  for (int i = i0 + tid; i < i1; i += 1024) {
+  {
+    // bounding box: per-thread, then per-wave (shuffles), then one LDS atomic per wave and axis
+    // (one atomic per coordinate serialises ~27 k updates on six addresses: 85 us -> measured below)
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    for (int i = i0 + tid; i < i1; i += 1024) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int v = in_coords[4 * i + 1 + a];
+        lo[a] = min(lo[a], v);
+        hi[a] = max(hi[a], v);
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const int v = in_coords[4 * i + 1 + a];
-      atomicMin(&bmin[a], v);
-      atomicMax(&bmax[a], v);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo[a] = min(lo[a], __shfl_xor(lo[a], off));
+        hi[a] = max(hi[a], __shfl_xor(hi[a], off));
+      }
+      if ((tid & 63) == 0) {
+        atomicMin(&bmin[a], lo[a]);
+        atomicMax(&bmax[a], hi[a]);
+      }
     }
   }
   __syncthreads();
