@@ -18,6 +18,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <atomic>
 #include <vector>
 
@@ -1231,12 +1232,25 @@ __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__
 // (~5e-16 absolute in d^2) of the minimum, where the two values differ by less than that.
 constexpr int CHM_ST = 64;    // sources per workgroup (16 per wave)
 constexpr int CHM_TT = 512;   // targets per LDS stage
+// A-operand rows of every target, once per call: (x, y, z, |t|^2) in f64
+__global__ void k_chamfer_pack(const float* __restrict__ tgt, int64_t n, double* __restrict__ t4g) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+  double* o = t4g + 4 * i;
+  o[0] = x;
+  o[1] = y;
+  o[2] = z;
+  o[3] = fma(z, z, fma(y, y, x * x));
+}
+
 __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restrict__ work,
                                                       const float* __restrict__ src,
                                                       const float* __restrict__ tgt,
+                                                      const double* __restrict__ t4g,
                                                       const float* __restrict__ T, int reduce_max,
                                                       double* __restrict__ partial) {
-  __shared__ double t4[CHM_TT * 4];
+  __shared__ __attribute__((aligned(16))) double t4[CHM_TT * 4];
   __shared__ double red[CHM_ST];
   const ChamferWork wk = work[blockIdx.x];
   const int tid = threadIdx.x;
@@ -1262,13 +1276,14 @@ __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restr
     const int tcount = min(CHM_TT, wk.tn - tbase);
     __syncthreads();
     for (int j = tid; j < CHM_TT; j += 256) {
-      double x = 0.0, y = 0.0, z = 0.0, n2 = INFINITY;  // rows past the segment never win
+      double2 xy = make_double2(0.0, 0.0), zn = make_double2(0.0, INFINITY);  // rows past the segment never win
       if (j < tcount) {
-        const float* tp = tgt + (wk.t0 + tbase + j) * 3;
-        x = tp[0]; y = tp[1]; z = tp[2];
-        n2 = fma(z, z, fma(y, y, x * x));
+        const double2* tp = reinterpret_cast<const double2*>(t4g + (wk.t0 + tbase + j) * 4);
+        xy = tp[0];
+        zn = tp[1];
       }
-      t4[4 * j + 0] = x; t4[4 * j + 1] = y; t4[4 * j + 2] = z; t4[4 * j + 3] = n2;
+      *reinterpret_cast<double2*>(&t4[4 * j]) = xy;
+      *reinterpret_cast<double2*>(&t4[4 * j + 2]) = zn;
     }
     __syncthreads();
     for (int t = 0; t < (tcount + 15) / 16; ++t) {
@@ -1647,7 +1662,7 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
   PoolBuf<ChamferWork> dwork;
   PoolBuf<int32_t> dslot;
   PoolBuf<int64_t> dcount;
-  PoolBuf<double> partial(work.size() + 1);
+  PoolBuf<double> partial(work.size() + 1), t4g;
   CS_REQUIRE(partial.p, CS_ERR_HIP, "cs_chamfer_1dir: scratch allocation failed");
   int rc = upload(dwork, work, s);
   if (!rc) rc = upload(dslot, slot_begin, s);
@@ -1658,9 +1673,19 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
   {
     ProfScope prof("chamfer", s, ch_flop);
     if (!work.empty()) {
-      if (mfma)
+      if (mfma) {
+        int64_t nt_rows = 0;
+        for (int p = 0; p < n_prob; ++p) nt_rows = std::max<int64_t>(nt_rows, h_toff[h_tgt_seg[p] + 1]);
+        if (!t4g.alloc((size_t)(nt_rows ? nt_rows : 1) * 4)) {
+          set_error("cs_chamfer_1dir: scratch allocation failed");
+          return CS_ERR_HIP;
+        }
+        if (nt_rows)
+          hipLaunchKernelGGL(k_chamfer_pack, dim3((unsigned)ceil_div(nt_rows, 256)), dim3(256), 0, s, d_tgt,
+                             nt_rows, t4g.p);
         hipLaunchKernelGGL(k_chamfer_mfma, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
-                           d_tgt, d_T, reduce_max, partial.p);
+                           d_tgt, t4g.p, d_T, reduce_max, partial.p);
+      }
       else
         hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
                            d_tgt, d_T, reduce_max, partial.p);
