@@ -186,43 +186,47 @@ __global__ __launch_bounds__(256) void k_symcut_select(
   const unsigned long long kth = s_prefix;  // value of the n_sel-th smallest key
   const int need_eq = s_remaining;          // how many keys == kth belong to the selection
 
-  // ordered compaction (ascending row): contiguous chunk per thread, two small scans
-  const int chunk = (n + 255) / 256;
-  const int i0 = tid * chunk, i1 = min(n, i0 + chunk);
-  int c_eq = 0;
-  for (int i = i0; i < i1; ++i) c_eq += keys[i] == kth;
-  int tot_unused;
-  scan_a[tid] = block_excl_scan256(c_eq, wsum, &tot_unused);
-  __syncthreads();
-  int eq_rank = scan_a[tid];
-  int c_sel = 0;
-  for (int i = i0; i < i1; ++i) {
-    const unsigned long long key = keys[i];
-    if (key < kth)
-      ++c_sel;
-    else if (key == kth) {
-      if (eq_rank < need_eq) ++c_sel;
-      ++eq_rank;
-    }
-  }
-  scan_b[tid] = block_excl_scan256(c_sel, wsum, &tot_unused);
-  __syncthreads();
+  // ordered compaction (ascending row).  Each wave owns a contiguous quarter of the rows and walks it 64
+  // rows at a time (coalesced key reads; ranks inside a step come from ballots): a counting pass, one
+  // exchange of the four waves' totals, then the emitting pass.
   {
-    int pos = scan_b[tid];
-    eq_rank = scan_a[tid];
-    for (int i = i0; i < i1; ++i) {
-      const unsigned long long key = keys[i];
-      bool take = key < kth;
-      if (key == kth) {
-        take = eq_rank < need_eq;
-        ++eq_rank;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = ((n + 3) / 4 + 63) / 64 * 64;
+    const int w0 = wave * q, w1 = min(n, w0 + q);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    int n_lt = 0, n_eq = 0;
+    for (int i = w0; i < w1; i += 64) {
+      const bool in = i + lane < w1;
+      const unsigned long long key = in ? keys[i + lane] : ~0ULL;
+      n_lt += __popcll(__ballot(in && key < kth));
+      n_eq += __popcll(__ballot(in && key == kth));
+    }
+    if (lane == 0) {
+      scan_a[wave] = n_lt;
+      scan_b[wave] = n_eq;
+    }
+    __syncthreads();
+    int eq_rank = 0, pos = 0;
+    for (int w = 0; w < wave; ++w) {
+      const int eq_taken = max(0, min(scan_b[w], need_eq - eq_rank));
+      pos += scan_a[w] + eq_taken;
+      eq_rank += scan_b[w];
+    }
+    for (int i = w0; i < w1; i += 64) {
+      const bool in = i + lane < w1;
+      const unsigned long long key = in ? keys[i + lane] : ~0ULL;
+      const bool lt = in && key < kth, eq = in && key == kth;
+      const unsigned long long eqm = __ballot(eq);
+      const bool take = lt || (eq && eq_rank + __popcll(eqm & below) < need_eq);
+      const unsigned long long tm = __ballot(take);
+      const int my = pos + __popcll(tm & below);
+      if (take && my < SYM_MAX_NN) {
+        pts[my][0] = (double)xyz[(base + i + lane) * 3 + 0];
+        pts[my][1] = (double)xyz[(base + i + lane) * 3 + 1];
+        pts[my][2] = (double)xyz[(base + i + lane) * 3 + 2];
       }
-      if (take && pos < SYM_MAX_NN) {
-        pts[pos][0] = (double)xyz[(base + i) * 3 + 0];
-        pts[pos][1] = (double)xyz[(base + i) * 3 + 1];
-        pts[pos][2] = (double)xyz[(base + i) * 3 + 2];
-        ++pos;
-      }
+      pos += __popcll(tm);
+      eq_rank += __popcll(eqm);
     }
   }
   if (tid == 0) nsel_g[blk] = n_sel;
