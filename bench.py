@@ -56,7 +56,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
-    from corsair_amd import _lib, harness, sharding, synth
+    from corsair_amd import _lib, harness, registration, sharding, synth
 
     _lib.require_gpu()
     # one process per GPU; CORSAIR_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
@@ -114,15 +114,17 @@ def main():
 
     def step(b):
         qs = pipe.embed_batch(q_dev[b], q_off[b])
+        ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
+        # host work that only needs the voxel counts goes here, while the convolutions are still running
+        q_anc = [registration.draw_anchors(qs.offsets[i + 1] - qs.offsets[i], 100, ids[i][0]) for i in range(BATCH)]
         top = _lib.to_host(pipe.retrieve(qs.desc, catalog.desc, 1)[:, 0])[0]
         cads = catalog.gather(top)
-        ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
         # force_gate: with random-init weights the part-cut acceptance gate (tuned to trained
         # features; sym_ransac_success is True for 993/993 queries in the reference's caches) never
         # passes, which would drop the K symmetric hypotheses -- 2/3 of the registration work -- from
         # the timed region.  The bench accepts the best-balanced anchor so every query runs
         # 1 + K (+4) RANSACs like the reference workload.  Parity tests use the real gate.
-        res = pipe.register(qs, cads, sym[top], anchor_ids=ids, force_gate=True)
+        res = pipe.register(qs, cads, sym[top], anchor_ids=ids, force_gate=True, query_anchors=q_anc)
         Tb, Tr, cdb, its = _lib.to_host(res.T_best, res.T_ransac, res.cd_best, res.iters)
         results.append((b, top, Tb, Tr, cdb, res.ok, its, res.n_problems))
 

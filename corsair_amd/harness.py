@@ -98,12 +98,14 @@ class Pipeline:
         return B.l2_topk(q_desc, lib_desc, k)
 
     # ---- registration (evaluation.py:297-331) -----------------------------------------------------
-    def register(self, queries, cads, syms, anchor_ids=None, use_symmetry=True, force_gate=False):
+    def register(self, queries, cads, syms, anchor_ids=None, use_symmetry=True, force_gate=False,
+                 query_anchors=None):
         """queries / cads: EmbeddedSets of equal length (pair p = query p vs cad p)."""
         c = self.cfg
         return R.sym_pose_batch(queries.F, queries.origin, queries.offsets, cads.F, cads.origin,
                                 cads.offsets, syms, c.k_nn, c.max_corr, 0, anchor_ids, 100,
-                                c.ransac_max_iter, c.ransac_confidence, use_symmetry, force_gate)
+                                c.ransac_max_iter, c.ransac_confidence, use_symmetry, force_gate,
+                                query_anchors)
 
 
 def concat_sets(sets):

@@ -123,10 +123,13 @@ def part_configs(K, pos_sym):
 
 def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_corr=0.20, seed=0,
                    anchor_ids=None, n_anchor=100, max_iter=100000, confidence=0.999,
-                   use_symmetry=True, force_gate=False):
+                   use_symmetry=True, force_gate=False, query_anchors=None):
     """baseF f32 [N0,16], xyz0 f32 [N0,3] (query voxels of all pairs, segment p = off0[p]:off0[p+1]);
     posF/xyz1/off1 likewise for the CAD side; pos_syms: symmetry label per pair.
-    anchor_ids[p] = (counter0, counter1) seeds the anchor draw of pair p (default (2p, 2p+1))."""
+    anchor_ids[p] = (counter0, counter1) seeds the anchor draw of pair p (default (2p, 2p+1)).
+    query_anchors: the query-side draws (draw_anchors(n0[p], n_anchor, anchor_ids[p][0]) for every p)
+    when the caller has already made them -- e.g. while the embedding kernels were still running; the
+    ~1 ms of host work would otherwise sit between the 5-NN and the part-cut launches."""
     dev = baseF.device
     P = len(off0) - 1
     off0 = [int(v) for v in off0]
@@ -155,7 +158,8 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
         Ks = [4 if int(pos_syms[p]) >= 2 else 2 for p in range(P)]
         if anchor_ids is None:
             anchor_ids = [(2 * p, 2 * p + 1) for p in range(P)]
-        anc0 = [draw_anchors(n0[p], n_anchor, anchor_ids[p][0]) for p in range(P)]
+        anc0 = query_anchors if query_anchors is not None else \
+            [draw_anchors(n0[p], n_anchor, anchor_ids[p][0]) for p in range(P)]
         anc1 = [draw_anchors(n1[p], n_anchor, anchor_ids[p][1]) for p in range(P)]
         cand = [p for p in range(P) if anc0[p] is not None and anc1[p] is not None]
         sel0 = np.zeros((P, 4, 3))
