@@ -279,6 +279,12 @@ def main():
             "roofline": roofline,
             "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         }
+        import ctypes
+        st = (ctypes.c_uint64 * 5)()
+        _lib.load().cs_ransac_prefilter_stats(st, 0)
+        out["ransac_prefilter"] = {"survivors": int(st[3]), "hypotheses": int(st[4]),
+                                   "note": "hypotheses whose f16 upper bound reached the best count and were "
+                                           "recounted exactly / all hypotheses evaluated (whole run incl. warmup)"}
         if overlap:
             out["two_batches_in_flight"] = {
                 "value": total_q / overlap[0], "unit": "queries/s", "ms_per_step": overlap[0] / args.steps * 1e3,

@@ -1230,8 +1230,9 @@ __global__ __launch_bounds__(256) void k_chamfer(const ChamferWork* __restrict__
 // four candidates of a source are re-evaluated with the canonical chain and the smallest is the
 // result -- equal to the exhaustive chain unless two targets are within the expansion's rounding
 // (~5e-16 absolute in d^2) of the minimum, where the two values differ by less than that.
-constexpr int CHM_ST = 64;    // sources per workgroup (16 per wave)
-constexpr int CHM_TT = 512;   // targets per LDS stage
+constexpr int CHM_NG = 4;               // 16-source groups per wave: every staged target row serves 256 sources
+constexpr int CHM_ST = 64 * CHM_NG;     // sources per workgroup
+constexpr int CHM_TT = 512;             // targets per LDS stage
 // A-operand rows of every target, once per call: (x, y, z, |t|^2) in f64
 __global__ void k_chamfer_pack(const float* __restrict__ tgt, int64_t n, double* __restrict__ t4g) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1256,22 +1257,23 @@ __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restr
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int col = lane & 15;  // source within the wave (B side); target row within a 16-row tile (A side)
+  const int col = lane & 15;  // source within a group (B side); target row within a 16-row tile (A side)
   const int kq = lane >> 4;   // k slot of the operands; row group of the results
-  const int sloc = wave * 16 + col;
-  const bool active = sloc < wk.sn;
   const float* Tp = T + (int64_t)wk.prob * 16;
-  double px = 0, py = 0, pz = 0;
-  {
-    const float* sp = src + (wk.s0 + (active ? sloc : 0)) * 3;
+  double px[CHM_NG], py[CHM_NG], pz[CHM_NG], bq[CHM_NG], best[CHM_NG];
+  int bidx[CHM_NG];
+#pragma unroll
+  for (int g = 0; g < CHM_NG; ++g) {
+    const int sloc = (wave * CHM_NG + g) * 16 + col;
+    const float* sp = src + (wk.s0 + (sloc < wk.sn ? sloc : 0)) * 3;
     const double x = sp[0], y = sp[1], z = sp[2];
-    px = fma((double)Tp[0], x, fma((double)Tp[1], y, fma((double)Tp[2], z, (double)Tp[3])));
-    py = fma((double)Tp[4], x, fma((double)Tp[5], y, fma((double)Tp[6], z, (double)Tp[7])));
-    pz = fma((double)Tp[8], x, fma((double)Tp[9], y, fma((double)Tp[10], z, (double)Tp[11])));
+    px[g] = fma((double)Tp[0], x, fma((double)Tp[1], y, fma((double)Tp[2], z, (double)Tp[3])));
+    py[g] = fma((double)Tp[4], x, fma((double)Tp[5], y, fma((double)Tp[6], z, (double)Tp[7])));
+    pz[g] = fma((double)Tp[8], x, fma((double)Tp[9], y, fma((double)Tp[10], z, (double)Tp[11])));
+    bq[g] = kq == 0 ? -2.0 * px[g] : (kq == 1 ? -2.0 * py[g] : (kq == 2 ? -2.0 * pz[g] : 1.0));
+    best[g] = INFINITY;
+    bidx[g] = -1;
   }
-  const double b = kq == 0 ? -2.0 * px : (kq == 1 ? -2.0 * py : (kq == 2 ? -2.0 * pz : 1.0));
-  double best = INFINITY;
-  int bidx = -1;
   for (int tbase = 0; tbase < wk.tn; tbase += CHM_TT) {
     const int tcount = min(CHM_TT, wk.tn - tbase);
     __syncthreads();
@@ -1288,28 +1290,35 @@ __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restr
     __syncthreads();
     for (int t = 0; t < (tcount + 15) / 16; ++t) {
       const double a = t4[(16 * t + col) * 4 + kq];
-      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      // acc[r] = |t|^2 - 2 p.t of target row 16 t + kq + 4 r and source col
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (acc[r] < best) {
-          best = acc[r];
-          bidx = tbase + 16 * t + kq + 4 * r;
+      for (int g = 0; g < CHM_NG; ++g) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[g], acc, 0, 0, 0);
+        // acc[r] = |t|^2 - 2 p.t of target row 16 t + kq + 4 r and source col of group g
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (acc[r] < best[g]) {
+            best[g] = acc[r];
+            bidx[g] = tbase + 16 * t + kq + 4 * r;
+          }
         }
       }
     }
   }
   // canonical distance of this lane's candidate, then the smallest of the source's four lanes
-  double d = INFINITY;
-  if (bidx >= 0) {
-    const float* tp = tgt + (wk.t0 + bidx) * 3;
-    const double dx = px - (double)tp[0], dy = py - (double)tp[1], dz = pz - (double)tp[2];
-    d = fma(dz, dz, fma(dy, dy, dx * dx));
+#pragma unroll
+  for (int g = 0; g < CHM_NG; ++g) {
+    double d = INFINITY;
+    if (bidx[g] >= 0) {
+      const float* tp = tgt + (wk.t0 + bidx[g]) * 3;
+      const double dx = px[g] - (double)tp[0], dy = py[g] - (double)tp[1], dz = pz[g] - (double)tp[2];
+      d = fma(dz, dz, fma(dy, dy, dx * dx));
+    }
+    d = fmin(d, __shfl_xor(d, 16));
+    d = fmin(d, __shfl_xor(d, 32));
+    const int sloc = (wave * CHM_NG + g) * 16 + col;
+    if (kq == 0) red[sloc] = sloc < wk.sn ? sqrt(d) : 0.0;
   }
-  d = fmin(d, __shfl_xor(d, 16));
-  d = fmin(d, __shfl_xor(d, 32));
-  if (kq == 0) red[sloc] = active ? sqrt(d) : 0.0;
   __syncthreads();
   for (int off = CHM_ST / 2; off > 0; off >>= 1) {
     if (tid < off) red[tid] = reduce_max ? fmax(red[tid], red[tid + off]) : red[tid] + red[tid + off];

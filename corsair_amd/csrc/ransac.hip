@@ -439,20 +439,24 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
 // Once a problem has a best inlier count, a hypothesis matters only if its own count can reach it
 // (otherwise it changes neither the best, nor the early-exit bound, nor the tie set).  The squared
 // residual is bilinear in hypothesis and pair quantities,
-//   |R s + t - q|^2 = |t|^2 + [1, 2 R^T t, -2 R, -2 t] . [|s|^2 + |q|^2, s, q (x) s, q]     (16 terms)
-// Every term is split into f16 hi + lo; hi*hi + hi*lo + lo*hi (47 products, K = 48) is three
-// v_mfma_f32_32x32x16_f16 per 32 x 32 tile (16x the f32 matrix rate) whose accumulator INPUT holds
-// |t|^2 - (thr^2 + eps_h): the sign of the result says whether the pair is within the INFLATED
-// threshold.  eps_h bounds |d~^2 - d^2| (k_ransac_hyp16), so the sign count is an UPPER bound of the
-// exact inlier count.  Hypotheses whose bound is below the carried best get count 0, the few
-// survivors go through the exact f32 kernel: results are unchanged bit for bit.
+//   |R s + t - q|^2 = |t|^2 + a . b,   a = [1, 2 R^T t, -2 R, -2 t],  b = [|s|^2 + |q|^2, s, q (x) s, q]   (16 terms)
+// The pair side is split into f16 hi + lo, the hypothesis side is rounded to f16 (a_hi): a_hi . b_hi +
+// a_hi . b_lo (K = 32) is two v_mfma_f32_32x32x16_f16 per 32 x 32 tile (16x the f32 matrix rate) whose
+// accumulator INPUT holds |t|^2 - (thr^2 + eps_h): the sign of the result says whether the pair is
+// within the INFLATED threshold.  eps_h bounds |d~^2 - d^2| (k_ransac_hyp16) -- including the dropped
+// (a - a_hi) . b, bounded per hypothesis with the per-problem maxima of |b_k| -- so the sign count is an
+// UPPER bound of the exact inlier count.  Hypotheses whose bound is below the carried best get count
+// 0, the few survivors go through the exact f32 kernel: results are unchanged bit for bit.
+// (The K = 48 form with a_lo . b_hi has a ~2.5x tighter eps_h but 3 MFMAs per tile: measured slower
+// end to end, DESIGN.md "What was tried".)
 // ------------------------------------------------------------------------------------------------
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-constexpr int PF_K = 48;        // halfs per operand row (96 B)
-constexpr int PF_PITCH = 56;    // halfs per LDS row (112 B = 7 slots of 16 B: conflict-free ds_read_b128)
+constexpr int PF_K = 16;        // halfs per hypothesis row (32 B): a_hi, used by both MFMAs
+constexpr int PF_PITCH = 40;    // halfs per pair row (80 B = 5 slots of 16 B: conflict-free ds_read_b128)
 constexpr int PF_ROWS = 192;    // pairs per LDS stage (6 MFMA row tiles)
 constexpr int PF_NG = 2;        // 32-hypothesis groups per wave (LDS fragments are reused NG times)
 constexpr int PF_HYP = 4 * 32 * PF_NG;  // hypotheses per workgroup
+constexpr int PF_STAT = 17;     // per-problem statistics of the pair image: smax, max |b_k| (k = 0..15)
 constexpr float PF_SMAX = 128.0f;       // point norm above which a problem bypasses the prefilter
                                         // (f16 range: |s|^2 + |q|^2 and q (x) s must stay below 65504)
 
@@ -465,27 +469,30 @@ __device__ __forceinline__ void split16(double v, _Float16* hi, _Float16* lo) {
 // rows of problem p in the f16 pair image: m rounded up to whole LDS stages
 __host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_ROWS - 1) / PF_ROWS * PF_ROWS; }
 
-// pair side: 112-B rows [bh(0..15) | bl(0..15) | bh(1..15), 0 | 8 x 0] in exactly the layout the
-// prefilter keeps in LDS (a stage is one contiguous 21-KiB copy); every problem is padded to whole
-// stages with rows whose d~^2 is +60000 (never counted).  smax[p] = largest point norm of problem p.
+// pair side: 80-B rows [bh(0..15) | bl(0..15) | 8 x 0] in exactly the layout the prefilter keeps in LDS
+// (a stage is one contiguous 15-KiB copy); every problem is padded to whole stages with rows whose d~^2
+// is +60000 (never counted).  stat[p] = {largest point norm, max |b_k| (k = 0..15)} of problem p as
+// float bit patterns (non-negative floats order like their bits), rounded up.
 // grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
 __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restrict__ probs,
                                                        const int64_t* __restrict__ off16,
                                                        const float* __restrict__ src,
                                                        const float* __restrict__ tgt,
                                                        _Float16* __restrict__ B16,
-                                                       unsigned* __restrict__ smax_bits) {
-  __shared__ float red[4];
+                                                       unsigned* __restrict__ stat) {
+  __shared__ float red[4][PF_STAT];
   const RansacProb pr = probs[blockIdx.y];
   const int mpad = (int)pf_padded(pr.m);
-  float mx = 0.f;
+  float mx[PF_STAT];
+#pragma unroll
+  for (int k = 0; k < PF_STAT; ++k) mx[k] = 0.f;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < mpad; j += gridDim.x * blockDim.x) {
     union {
       _Float16 h[PF_PITCH];
-      uint4 v[7];
+      uint4 v[5];
     } row;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) row.v[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = 0; k < 5; ++k) row.v[k] = make_uint4(0u, 0u, 0u, 0u);
     if (j < pr.m) {
       const int64_t i = pr.off + j;
       const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
@@ -506,42 +513,50 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
-        if (ok) split16(b[k], &hi, &lo);
+        if (ok) {
+          split16(b[k], &hi, &lo);
+          mx[1 + k] = fmaxf(mx[1 + k], __double2float_ru(fabs(b[k])));
+        }
         row.h[k] = hi;
         row.h[16 + k] = lo;
-        if (k) row.h[31 + k] = hi;
       }
-      mx = fmaxf(mx, mag);
+      mx[0] = fmaxf(mx[0], mag);
     } else {
       row.h[0] = (_Float16)60000.0f;  // pairs with a_0 = 1
     }
     uint4* dst = reinterpret_cast<uint4*>(B16 + (off16[blockIdx.y] + j) * PF_PITCH);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) dst[k] = row.v[k];
+    for (int k = 0; k < 5; ++k) dst[k] = row.v[k];
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  for (int k = 0; k < PF_STAT; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = mx[k];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (mx > 0.f) atomicMax(&smax_bits[blockIdx.y], __float_as_uint(mx));  // non-negative floats order like uints
+  if (threadIdx.x < PF_STAT) {
+    const int k = threadIdx.x;
+    const float m = fmaxf(fmaxf(red[0][k], red[1][k]), fmaxf(red[2][k], red[3][k]));
+    if (m > 0.f) atomicMax(&stat[blockIdx.y * PF_STAT + k], __float_as_uint(m));
   }
 }
 
-// hypothesis side: row = [ah(0..15) | ah(0..15) | al(1..15), 0] and the accumulator input
+// hypothesis side: row = a_hi(0..15) (f16 roundings of a) and the accumulator input
 //   c_h = |t|^2 - (thr^2 + eps_h).
-// eps_h >= |d~^2 - d^2| where d^2 is what the exact kernel computes and d~^2 the f16 pipeline:
-//   * 47 products, exact in f32; their accumulation rounds (or truncates) at most 48 times relative
-//     to sum_k |a_k b_k| <= sqrt(3) (|s| + |q| + |t|)^2 =: sqrt(3) W            <= 48 * 2^-23 * sqrt(3) W
-//   * dropped lo*lo products and the residuals of the hi+lo splits      <= 3 * 2^-22 * sqrt(3) W + 2^-25 (2 W + 59)
+// eps_h >= |d~^2 - d^2| where d^2 is what the exact kernel computes and d~^2 the f16 pipeline
+// c_h + sum_k a_hi_k (b_hi_k + b_lo_k):
+//   * 32 products, exact in f32; their accumulation rounds (or truncates) at most 33 times relative
+//     to sum_k |a_k b_k| <= sqrt(3) (|s| + |q| + |t|)^2 =: sqrt(3) W            <= 33 * 2^-23 * sqrt(3) W
+//   * the residuals of the hi+lo splits of b                            <= 2^-22 * sqrt(3) W + 2^-25 (2 W + 59)
 //   * the exact kernel's own f32 rounding of d^2                        <= 2^-20 W
 //   => < 3e-5 W + 2e-6; charged 1.2e-4 W + 1e-5 (4x margin; validated by CS_RANSAC_CHECK runs)
+//   * the dropped (a - a_hi) . b                      <= sum_k |a_k - a_hi_k| max_pairs |b_k|   (stat[p])
 //   * |R s|^2 = |s|^2 only up to the orthonormality defect E = R^T R - I:    <= 3 max|E| smax^2
 // with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
 // a zero row: every pair counts, it always survives to the exact kernel.
 __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float* __restrict__ hyp,
-                               const unsigned* __restrict__ smax_bits, int it0, int bcount, int bmax,
+                               const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
                                float thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -556,7 +571,7 @@ __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float
     for (int b = 0; b < 3; ++b) R[a][b] = (double)hp[(int64_t)(4 * a + b) * bmax];
     t[a] = (double)hp[(int64_t)(4 * a + 3) * bmax];
   }
-  const double smax = (double)__uint_as_float(smax_bits[p]);
+  const double smax = (double)__uint_as_float(stat[p * PF_STAT]);
   const double tt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
   const double tn = sqrt(tt);
   double a[16];
@@ -582,22 +597,20 @@ __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float
   for (int k = 0; k < 16; ++k) usable = usable && fabs(a[k]) < 6.0e4;  // false for NaN
   union {
     _Float16 h[PF_K];
-    uint4 v[6];
+    uint4 v[2];
   } row;
+  double drop = 0.0;  // sum_k |a_k - a_hi_k| max |b_k|
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
-    if (usable) split16(a[k], &hi, &lo);
+    const _Float16 hi = usable ? (_Float16)a[k] : (_Float16)0.0f;
     row.h[k] = hi;
-    row.h[16 + k] = hi;
-    if (k) row.h[31 + k] = lo;
+    if (usable) drop += fabs(a[k] - (double)hi) * (double)__uint_as_float(stat[p * PF_STAT + 1 + k]);
   }
-  row.h[47] = (_Float16)0.0f;
   uint4* dst = reinterpret_cast<uint4*>(A16 + ((int64_t)p * bmax + h) * PF_K);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) dst[k] = row.v[k];
+  dst[0] = row.v[0];
+  dst[1] = row.v[1];
   const double w = 2.0 * smax + tn;
-  const double eps = 1.2e-4 * w * w + 1.0e-5 + 3.0 * dev * smax * smax;
+  const double eps = 1.2e-4 * w * w + 1.0e-5 + 3.0 * dev * smax * smax + 1.000001 * drop;
   // rounded towards -inf so that the f32 value never tightens the test
   c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - ((double)thr2 + eps)) : -INFINITY;
 }
@@ -611,15 +624,16 @@ __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float
 // B[k = 8(l>>5) .. +8)][col l&31]; D as for the f32 shape.  rows = pairs (LDS, shared by the four
 // waves), cols = hypotheses (registers, PF_NG groups of 32 per wave).
 //
-// Staging: a stage is PF_ROWS rows = 21 KiB, contiguous in the pair image, copied global -> LDS by
-// 21 LDS-DMA instructions of 1 KiB (global_load_lds_dwordx4: no staging registers, no ds_write); the
+// Staging: a stage is PF_ROWS rows = 15 KiB, contiguous in the pair image, copied global -> LDS by
+// 15 LDS-DMA instructions of 1 KiB (global_load_lds_dwordx4: no staging registers, no ds_write); the
 // copy of stage s+1 is in flight while stage s is computed.
 //
-// Inner loop: units k = (row tile t, hypothesis group g), 12 per stage.  The three MFMAs of unit k are
+// Inner loop: units k = (row tile t, hypothesis group g), 12 per stage.  The two MFMAs of unit k are
 // issued interleaved with the sign extraction (16 x v_alignbit into a per-lane history word, one VALU
 // op per pair) of unit k-2, held in another of three rotating accumulator sets: a result is first
-// read a whole unit (>= 96 cycles) after the MFMA that wrote it, beyond the 11 wait states the
-// hardware requires.  The unit is one asm block: the compiler's scheduler does not keep this order
+// read a whole unit (>= 64 cycles) after the MFMA that wrote it, beyond the 11 wait states the
+// hardware requires.  The VALU side is the longer one (v_alignbit_b32 issues every ~4.5 cycles per
+// SIMD, tools/ubench/valu_rate.hip: 16 x 4.5 = 72 cycles against 64 for the MFMAs).  The unit is one asm block: the compiler's scheduler does not keep this order
 // (it hoists the dependent VALU ops and pays s_nop 10 per unit).
 __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __restrict__ probs,
                                                           const int64_t* __restrict__ off16,
@@ -633,8 +647,8 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
                                                           unsigned long long* __restrict__ trace) {
   const unsigned long long t_start = trace ? wall_clock64() : 0ULL;
   const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ULL;
-  constexpr int STAGE_BYTES = PF_ROWS * PF_PITCH * 2;  // 21504
-  constexpr int STAGE_KIB = STAGE_BYTES / 1024;        // 21 LDS-DMA instructions
+  constexpr int STAGE_BYTES = PF_ROWS * PF_PITCH * 2;  // 15360
+  constexpr int STAGE_KIB = STAGE_BYTES / 1024;        // 15 LDS-DMA instructions
   static_assert(STAGE_BYTES % 1024 == 0, "a stage must be whole 1-KiB LDS-DMA instructions");
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
   const int xcd = blockIdx.x & 7;
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
   const int col = lane & 31;
   const int h0 = tile * PF_HYP + wave * 32 * PF_NG;
   const bool wave_live = h0 < bcount && it0 + h0 < pr.est_k;
-  f16x8 bop[PF_NG][3];
+  f16x8 bop[PF_NG];
   f32x16 cin[PF_NG];
 #pragma unroll
   for (int g = 0; g < PF_NG; ++g) {
@@ -663,8 +677,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
     int hh = h0 + 32 * g + col;
     if (hh >= bcount || it0 + hh >= pr.est_k) hh = wave_live ? h0 : 0;
     const _Float16* row = A16 + ((int64_t)p * bmax + hh) * PF_K + 8 * half;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) bop[g][m] = *reinterpret_cast<const f16x8*>(row + 16 * m);
+    bop[g] = *reinterpret_cast<const f16x8*>(row);
     const float c = c_h[(int64_t)p * bmax + hh];
 #pragma unroll
     for (int r = 0; r < 16; ++r) cin[g][r] = c;
@@ -698,27 +711,26 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
   f32x16 S0, S1 = zero16, S2 = zero16;  // +0: the first two (dummy) extractions shift in zeros
 #define PF_UNIT(DST, SRC, G, A, COUNT) \
   asm volatile( \
-      "v_mfma_f32_32x32x16_f16 %0, %2, %5, %8\n\t" \
+      "v_mfma_f32_32x32x16_f16 %0, %2, %4, %6\n\t" \
+      "v_alignbit_b32 %1, %1, %7, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %8, 31\n\t" \
       "v_alignbit_b32 %1, %1, %9, 31\n\t" \
       "v_alignbit_b32 %1, %1, %10, 31\n\t" \
       "v_alignbit_b32 %1, %1, %11, 31\n\t" \
       "v_alignbit_b32 %1, %1, %12, 31\n\t" \
       "v_alignbit_b32 %1, %1, %13, 31\n\t" \
       "v_alignbit_b32 %1, %1, %14, 31\n\t" \
-      "v_mfma_f32_32x32x16_f16 %0, %3, %6, %0\n\t" \
+      "v_mfma_f32_32x32x16_f16 %0, %3, %5, %0\n\t" \
       "v_alignbit_b32 %1, %1, %15, 31\n\t" \
       "v_alignbit_b32 %1, %1, %16, 31\n\t" \
       "v_alignbit_b32 %1, %1, %17, 31\n\t" \
       "v_alignbit_b32 %1, %1, %18, 31\n\t" \
       "v_alignbit_b32 %1, %1, %19, 31\n\t" \
       "v_alignbit_b32 %1, %1, %20, 31\n\t" \
-      "v_mfma_f32_32x32x16_f16 %0, %4, %7, %0\n\t" \
       "v_alignbit_b32 %1, %1, %21, 31\n\t" \
-      "v_alignbit_b32 %1, %1, %22, 31\n\t" \
-      "v_alignbit_b32 %1, %1, %23, 31\n\t" \
-      "v_alignbit_b32 %1, %1, %24, 31" \
+      "v_alignbit_b32 %1, %1, %22, 31" \
       : "=&v"(DST), "+v"(bits[G]) \
-      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(bop[G][0]), "v"(bop[G][1]), "v"(bop[G][2]), \
+      : "v"(A[0]), "v"(A[1]), "v"(bop[G]), "v"(bop[G]), \
         "v"(cin[G]), "v"(SRC[0]), "v"(SRC[1]), "v"(SRC[2]), "v"(SRC[3]), "v"(SRC[4]), "v"(SRC[5]), \
         "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
         "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15])); \
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
   {                                                                                               \
     const _Float16* arow_ = reinterpret_cast<const _Float16*>(lds + buf * STAGE_BYTES) +          \
                             ((TILE) * 32 + col) * PF_PITCH + 8 * half;                            \
-    _Pragma("unroll") for (int m = 0; m < 3; ++m) A[m] =                                          \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) A[m] =                                          \
         *reinterpret_cast<const f16x8*>(arow_ + 16 * m);                                          \
   }
   if (beg < end) issue_stage(0, beg);
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
     if (wave_live) {
       // unit k writes set k % 3 and extracts set (k + 1) % 3 = unit k-2 = (tile t-1, same group);
       // 32 fresh sign bits are counted whenever tile t-1 is odd
-      f16x8 aX[3], aY[3];
+      f16x8 aX[2], aY[2];
       PF_LOAD(aX, 0)
       PF_LOAD(aY, 1)
       PF_UNIT(S0, S1, 0, aX, true)
@@ -1235,10 +1247,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   PoolBuf<int64_t> off16(n_prob + 1);
   PoolBuf<float> c_h(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
-  PoolBuf<unsigned> smax_bits(n_prob);
+  PoolBuf<unsigned> pf_stat((size_t)n_prob * PF_STAT);
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
-  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && smax_bits.p &&
+  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && pf_stat.p &&
                  exact_dbg.p && chk_stats.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   std::vector<int32_t> h_surv(n_prob), h_xcd;
@@ -1257,14 +1269,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     CS_LAUNCH_CHECK();
   }
   if (pf_alloc) {
-    CS_HIP_CHECK(hipMemsetAsync(smax_bits.p, 0, sizeof(unsigned) * n_prob, s));
+    CS_HIP_CHECK(hipMemsetAsync(pf_stat.p, 0, sizeof(unsigned) * n_prob * PF_STAT, s));
     CS_HIP_CHECK(hipMemsetAsync(chk_stats.p, 0, sizeof(unsigned long long) * 4, s));
     int pblocks = (int)ceil_div(m_max > 0 ? m_max : 1, 256);
     if (pblocks > 64) pblocks = 64;
     CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
                                 hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                       d_probs, off16.p, d_src, d_tgt, B16.p, smax_bits.p);
+                       d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
     CS_LAUNCH_CHECK();
   }
   // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
@@ -1366,13 +1378,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (psplits > 16) psplits = 16;
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, s, d_probs, hyp.p, smax_bits.p, it0, b, bmax, thr2, A16.p, c_h.p);
+                         0, s, d_probs, hyp.p, pf_stat.p, it0, b, bmax, thr2, A16.p, c_h.p);
       if (psplits > 1)
         CS_HIP_CHECK(hipMemset2DAsync(cnt_up.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                       n_prob, s));
       {
-        // 94 FLOP per (hypothesis, pair): the 47 multiply-adds of the hi/lo expansion
-        ProfScope prof("ransac_pre", s, 94.0 * eval_pairs);
+        // 64 FLOP per (hypothesis, pair): the 32 multiply-adds of the a_hi (b_hi + b_lo) expansion
+        ProfScope prof("ransac_pre", s, 64.0 * eval_pairs);
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
         hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, d_probs, off16.p, B16.p,
                            A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob, pslots, ptiles, cnt_up.p,

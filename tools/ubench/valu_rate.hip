@@ -4,10 +4,11 @@
 #include <stdio.h>
 #define REP16(x) x x x x x x x x x x x x x x x x
 template <int MODE>
-__global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr) {
+__global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr, unsigned long long* clk) {
   unsigned a = threadIdx.x, b = threadIdx.x * 3u, c = 5u, d = 7u;
   float f0 = (float)threadIdx.x, f1 = f0 * 0.5f;
   int cnt = 0;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
     if (MODE == 0) {  // dependent alignbit chain
       REP16(asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a) : "v"(b));)
@@ -31,31 +32,55 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr) {
       REP16(asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));)
     } else if (MODE == 8) {  // v_lshl_add_u32 dependent
       REP16(asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b));)
+    } else if (MODE == 10) {  // fma dependent
+      REP16(asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f0) : "v"(f1));)
+    } else if (MODE == 11) {  // v_perm_b32 dependent, literal selector
+      REP16(asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(0x0b070c0cu));)
+    } else if (MODE == 12) {  // v_bcnt accumulate
+      REP16(asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a) : "v"(b));)
+    } else if (MODE == 13) {  // v_xor VOP2 dependent
+      REP16(asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b));)
+    } else if (MODE == 14) {  // alignbit with SGPR shift operand
+      REP16(asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(31));)
     } else if (MODE == 9) {  // v_alignbit independent outputs (no chain), 16 distinct
       REP16(asm volatile("v_alignbit_b32 %0, %1, %2, 31" : "=v"(a) : "v"(b), "v"(c));)
     }
   }
-  out[blockIdx.x * 256 + threadIdx.x] = a + c + d + cnt + (unsigned)f1;
+  asm volatile("" : "+v"(a), "+v"(c), "+v"(d), "+v"(cnt));
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) {
+    clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = c1 - c0;
+    clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a + c + d + cnt + (unsigned)f1 + (unsigned)f0;
 }
 template <int MODE>
 void run(const char* name, int per_rep) {
   unsigned* out;
   hipMalloc(&out, 1024 * 256 * 4);
+  unsigned long long* clk;
+  hipMalloc(&clk, 1024 * 4 * 2 * 8);
   const int iters = 20000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<MODE><<<1024, 256>>>(out, 100, 1.0f);
+  k<MODE><<<1024, 256>>>(out, 100, 1.0f, clk);
   hipEventRecord(e0);
-  k<MODE><<<1024, 256>>>(out, iters, 1.0f);  // 1024 blocks of 4 waves: 4 blocks per CU = 4 waves per SIMD
+  k<MODE><<<1024, 256>>>(out, iters, 1.0f, clk);  // 1024 blocks of 4 waves: 4 blocks per CU = 4 waves per SIMD
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   // per SIMD: 4 waves x iters x 16 x per_rep instructions
   double inst = 4.0 * iters * 16.0 * per_rep;
-  double cyc = ms * 1e-3 * 2.4e9;
-  printf("%-34s %8.3f ms  %.2f cycles per wave-instruction (4 waves/SIMD, 2.4 GHz assumed)\n", name, ms, cyc / inst);
+  static unsigned long long h[1024 * 4 * 2];
+  hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+  double cs = 0, rs = 0;
+  for (int i = 0; i < 1024 * 4; ++i) { cs += (double)h[2 * i]; rs += (double)h[2 * i + 1]; }
+  const double ghz = cs / rs * 0.1;  // s_memrealtime ticks at 100 MHz
+  double cyc = ms * 1e-3 * ghz * 1e9;
+  printf("%-34s %8.3f ms  clock %.3f GHz  %.2f cycles per wave-instruction per SIMD (4 waves/SIMD)\n", name, ms, ghz, cyc / inst);
+  hipFree(clk);
   hipFree(out);
 }
 int main() {
@@ -69,5 +94,10 @@ int main() {
   run<6>("v_bfi dependent", 1);
   run<7>("v_and_or dependent", 1);
   run<8>("v_lshl_add dependent", 1);
+  run<10>("v_fma_f32 dependent", 1);
+  run<11>("v_perm_b32 dependent", 1);
+  run<12>("v_bcnt_u32_b32 accumulate", 1);
+  run<13>("v_xor_b32 dependent", 1);
+  run<14>("alignbit, sgpr shift", 1);
   return 0;
 }
