@@ -77,6 +77,12 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// adds work units to a family without bracketing a launch (the units of a launch enqueued earlier)
+void prof_add_units(const char* name, double units);
+// A second, lowest-priority stream of the calling thread (created on first use, lives as long as the
+// process) for work that may overlap the caller's stream; nullptr if it cannot be created.
+hipStream_t side_stream();
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- coordinate packing ---------------------------------------------------------------

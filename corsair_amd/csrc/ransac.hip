@@ -61,6 +61,19 @@ struct RansacProb {
   float best_T[12];
 };
 
+// The kernels of a round's front half (hypotheses, f16 rows, prefilter) may run while the previous
+// round's scan kernels update est_k / done (cs_ransac_batch): they read the two fields with relaxed
+// atomic loads and only use them to skip work -- either value is safe (est_k only shrinks, done only
+// rises), the scan kernels decide with the final state.
+__device__ __forceinline__ RansacProb prob_view(const RansacProb* probs, int p) {
+  RansacProb v = {};
+  v.off = probs[p].off;
+  v.m = probs[p].m;
+  v.est_k = __atomic_load_n(&probs[p].est_k, __ATOMIC_RELAXED);
+  v.done = __atomic_load_n(&probs[p].done, __ATOMIC_RELAXED);
+  return v;
+}
+
 __host__ __device__ static inline uint64_t rng_u64(uint64_t seed, uint64_t itr, uint64_t j) {
   uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (itr * 64ULL + j + 1ULL);
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -137,7 +150,7 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
 }
 
 // hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
-__global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict__ probs,
+__global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     const float4* __restrict__ pair32, int it0,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed,
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* __restrict
   if (p < 0) return;
   const int h = (item - slot * tiles) * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
-  const RansacProb pr = probs[p];
+  const RansacProb pr = prob_view(probs, p);
   const int itr = it0 + h;
   if (pr.done || itr >= pr.est_k) return;
   const uint32_t m = (uint32_t)pr.m;
@@ -555,13 +568,13 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 //   * |R s|^2 = |s|^2 only up to the orthonormality defect E = R^T R - I:    <= 3 max|E| smax^2
 // with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
 // a zero row: every pair counts, it always survives to the exact kernel.
-__global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float* __restrict__ hyp,
+__global__ void k_ransac_hyp16(const RansacProb* probs, const float* __restrict__ hyp,
                                const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
                                float thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
-  const RansacProb pr = probs[p];
+  const RansacProb pr = prob_view(probs, p);
   if (pr.done || it0 + h >= pr.est_k) return;
   const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
   double R[3][3], t[3];
@@ -635,7 +648,7 @@ __global__ void k_ransac_hyp16(const RansacProb* __restrict__ probs, const float
 // hardware requires.  The VALU side is the longer one (v_alignbit_b32 issues every ~4.5 cycles per
 // SIMD, tools/ubench/valu_rate.hip: 16 x 4.5 = 72 cycles against 64 for the MFMAs).  The unit is one asm block: the compiler's scheduler does not keep this order
 // (it hoists the dependent VALU ops and pays s_nop 10 per unit).
-__global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __restrict__ probs,
+__global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* probs,
                                                           const int64_t* __restrict__ off16,
                                                           const _Float16* __restrict__ B16,
                                                           const _Float16* __restrict__ A16,
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* __re
   if (p < 0) return;
   const int tile = inner / splits;
   const int split = inner - tile * splits;
-  const RansacProb pr = probs[p];
+  const RansacProb pr = prob_view(probs, p);
   if (pr.done) return;
   if (it0 + tile * PF_HYP >= pr.est_k || tile * PF_HYP >= bcount) return;
   const int tid = threadIdx.x;
@@ -1233,7 +1246,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   CS_REQUIRE(state.p && h_state, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   PoolBuf<float> pk((size_t)tot1 * 6);
   PoolBuf<float4> pair32((size_t)tot1 * 2);
-  PoolBuf<float> hyp((size_t)n_prob * 12 * bmax);
+  PoolBuf<float> hyp((size_t)2 * n_prob * 12 * bmax);  // hypotheses, one set per round parity
   PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax), cand((size_t)n_prob * bmax);
   PoolBuf<unsigned long long> cand_err((size_t)n_prob * bmax);
   CS_REQUIRE(pk.p && pair32.p && hyp.p && res_cnt.p && cand.p && cand_err.p,
@@ -1243,24 +1256,20 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   std::vector<int64_t> h_off16(n_prob + 1, 0);
   for (int p = 0; p < n_prob; ++p) h_off16[p + 1] = h_off16[p] + pf_padded(hp[p].m);
   const int64_t rows16 = h_off16[n_prob] ? h_off16[n_prob] : 1;
-  PoolBuf<_Float16> B16(pf_alloc ? (size_t)rows16 * PF_PITCH : 8), A16(pf_alloc ? (size_t)n_prob * bmax * PF_K : 8);
+  PoolBuf<_Float16> B16(pf_alloc ? (size_t)rows16 * PF_PITCH : 8), A16(pf_alloc ? (size_t)2 * n_prob * bmax * PF_K : 8);
   PoolBuf<int64_t> off16(n_prob + 1);
-  PoolBuf<float> c_h(pf_alloc ? (size_t)n_prob * bmax : 1);
-  PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
+  PoolBuf<float> c_h(pf_alloc ? (size_t)2 * n_prob * bmax : 1);
+  PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)2 * n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned> pf_stat((size_t)n_prob * PF_STAT);
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
   CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && pf_stat.p &&
                  exact_dbg.p && chk_stats.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
-  std::vector<int32_t> h_surv(n_prob), h_xcd;
-  int pslots = 1;
-  // two copies of the placement table, used alternately: the hypotheses of the next chunk are
-  // enqueued with this round's table while the next round uploads its own
+  std::vector<int32_t> h_surv(n_prob), h_xcd[2];
+  // placement tables, one per round parity (8 x n_prob entries each)
   PoolBuf<int32_t> xcd_buf((size_t)16 * n_prob);
   CS_REQUIRE(xcd_buf.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
-  int32_t* xcd_prob = xcd_buf.p;
-  int round = 0;
   CS_HIP_CHECK(hipMemcpyAsync(d_probs, hp.data(), sizeof(RansacProb) * n_prob,
                               hipMemcpyHostToDevice, s));
   if (total > 0) {
@@ -1296,21 +1305,106 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     ~Event() {
       if (e) (void)hipEventDestroy(e);
     }
-  } round_done;
+  } round_done, front_done[2];
   CS_HIP_CHECK(hipEventCreateWithFlags(&round_done.e, hipEventDisableTiming));
-  bool hyp_ready = false;  // the hypotheses of the chunk at it0 are already enqueued
-  int max_surv_prev = 1 << 30;  // survivors per problem in the previous prefiltered round (unknown: many)
-  auto launch_hyp = [&](int first, int count) {
-    ProfScope prof("ransac_hyp", s);
-    const int htiles = (count + 255) / 256;
-    hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, s, d_probs,
-                       pair32.p, first, count, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp.p);
+  CS_HIP_CHECK(hipEventCreateWithFlags(&front_done[0].e, hipEventDisableTiming));
+  CS_HIP_CHECK(hipEventCreateWithFlags(&front_done[1].e, hipEventDisableTiming));
+  // A round = front half (hypotheses, f16 rows, prefilter: independent of the carried best) + back
+  // half (survivors, exact counts, scans: the sequential RANSAC state).  The front half of round i+1
+  // is enqueued on a second, low-priority stream before the host waits for round i, so it fills the
+  // GPU while the back half of round i (many small dependent kernels) and the host turnaround run.
+  // Its skip tests read est_k / done while they may be updated (prob_view); its placement table is
+  // built from the state one round earlier: finished problems cost a few empty workgroups.
+  const char* env_ov = getenv("CS_RANSAC_OVERLAP");
+  hipStream_t side = (env_ov && env_ov[0] == '0') ? nullptr : side_stream();
+  struct Front {
+    int it0 = 0, b = 0, par = 0;
+    bool pf = false, on_side = false;
   };
-  int it0 = 0;
-  while (it0 < max_iter) {
+  auto chunk_of = [&](int it0) {
     int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
-    if (b > max_iter - it0) b = max_iter - it0;
-    const bool pf = pf_alloc && it0 >= pf_from;
+    return b > max_iter - it0 ? max_iter - it0 : b;
+  };
+  auto enqueue_front = [&](int it0, int par, hipStream_t st) -> Front {
+    Front f;
+    f.it0 = it0;
+    f.b = chunk_of(it0);
+    f.par = par;
+    f.pf = pf_alloc && it0 >= pf_from;
+    f.on_side = st != s;
+    const int b = f.b;
+    // deal the live problems to the 8 XCDs, longest first onto the least loaded XCD
+    std::vector<int> order;
+    for (int p = 0; p < n_prob; ++p)
+      if (!hp[p].done && hp[p].est_k > it0) order.push_back(p);
+    const int live = (int)order.size();
+    std::sort(order.begin(), order.end(), [&](int a, int c) { return hp[a].m > hp[c].m; });
+    std::vector<std::vector<int>> lists(8);
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p : order) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      lists[best].push_back(p);
+      load[best] += pf_padded(hp[p].m);
+    }
+    int pslots = 1;
+    for (int x = 0; x < 8; ++x) pslots = std::max(pslots, (int)lists[x].size());
+    std::vector<int32_t>& tab = h_xcd[par];
+    tab.assign((size_t)8 * pslots, -1);
+    for (int x = 0; x < 8; ++x)
+      for (size_t i = 0; i < lists[x].size(); ++i) tab[(size_t)x * pslots + i] = lists[x][i];
+    int32_t* xcd_prob = xcd_buf.p + (size_t)par * 8 * n_prob;
+    (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, st);
+    float* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
+    {
+      ProfScope prof("ransac_hyp", st);
+      const int htiles = (b + 255) / 256;
+      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
+                         pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
+    }
+    if (f.pf) {
+      _Float16* A16_r = A16.p + (size_t)par * n_prob * bmax * PF_K;
+      float* c_h_r = c_h.p + (size_t)par * n_prob * bmax;
+      int32_t* cnt_up_r = cnt_up.p + (size_t)par * n_prob * bmax;
+      const int ptiles = (b + PF_HYP - 1) / PF_HYP;
+      // 1024 workgroups are resident (4 per CU): split the pair range until there are >= 8 rounds of
+      // workgroups, as long as a workgroup keeps >= 8 stages
+      int psplits = (int)((8 * 1024 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
+      if (psplits < 1) psplits = 1;
+      if (psplits > 16) psplits = 16;
+      while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
+      hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
+                         0, st, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r);
+      if (psplits > 1)
+        (void)hipMemset2DAsync(cnt_up_r, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b, n_prob, st);
+      {
+        ProfScope prof("ransac_pre", st);  // work units are added by the back half (state known there)
+        const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
+        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+                           A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, pslots, ptiles, cnt_up_r,
+                           (trace_it0 == it0) ? trace.p : nullptr);
+        if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
+      }
+    }
+    if (f.on_side) (void)hipEventRecord(front_done[par].e, st);
+    return f;
+  };
+
+  int max_surv_prev = 1 << 30;  // survivors per problem in the previous prefiltered round (unknown: many)
+  Front cur = enqueue_front(0, 0, s);
+  CS_LAUNCH_CHECK();
+  bool side_pending = false;  // the side stream holds work the main stream has not waited for
+  int side_par = 0;
+  while (true) {
+    const int it0 = cur.it0, b = cur.b;
+    const bool pf = cur.pf;
+    const float* hyp_r = hyp.p + (size_t)cur.par * n_prob * 12 * bmax;
+    const int32_t* cnt_up_r = cnt_up.p + (size_t)cur.par * n_prob * bmax;
+    if (cur.on_side) {
+      CS_HIP_CHECK(hipStreamWaitEvent(s, front_done[cur.par].e, 0));
+      side_pending = false;
+    }
     bool err_known = false;  // the fixed-point errors of all candidates are already in cand_err (by hypothesis)
     const int tiles = (b + 127) / 128;
     // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
@@ -1319,38 +1413,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (splits < 1) splits = 1;
     if (splits > 16) splits = 16;
     while (splits > 1 && m_max / splits < 4 * RC_CHUNK) --splits;
-    // deal the live problems to the 8 XCDs, longest first onto the least loaded XCD
-    int live = 0;  // problems still iterating in this round
-    {
-      std::vector<int> order;
-      for (int p = 0; p < n_prob; ++p)
-        if (!hp[p].done && hp[p].est_k > it0) order.push_back(p);
-      live = (int)order.size();
-      std::sort(order.begin(), order.end(), [&](int a, int c) { return hp[a].m > hp[c].m; });
-      std::vector<std::vector<int>> lists(8);
-      int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int p : order) {
-        int best = 0;
-        for (int x = 1; x < 8; ++x)
-          if (load[x] < load[best]) best = x;
-        lists[best].push_back(p);
-        load[best] += pf_padded(hp[p].m);
-      }
-      pslots = 0;
-      for (int x = 0; x < 8; ++x) pslots = std::max(pslots, (int)lists[x].size());
-      if (pslots < 1) pslots = 1;
-      h_xcd.assign((size_t)8 * pslots, -1);
-      for (int x = 0; x < 8; ++x)
-        for (size_t i = 0; i < lists[x].size(); ++i) h_xcd[(size_t)x * pslots + i] = lists[x][i];
-    }
-    xcd_prob = xcd_buf.p + (size_t)(round++ & 1) * 8 * n_prob;
-    CS_HIP_CHECK(hipMemcpyAsync(xcd_prob, h_xcd.data(), sizeof(int32_t) * 8 * pslots,
-                                hipMemcpyHostToDevice, s));
-    if (!hyp_ready) launch_hyp(it0, b);
-    hyp_ready = false;
     CS_HIP_CHECK(hipMemsetAsync(d_nsurv, 0, st_surv + 8, s));  // survivor counts and n_active
-    // algorithmic work of this chunk: 30 FLOP per (evaluated hypothesis, correspondence)
-    // (transform 18 + squared distance 8 + compare/accumulate)
+    // algorithmic work of this chunk (hp is the state before it): 30 FLOP per (evaluated hypothesis,
+    // correspondence) for the exact count (transform 18 + squared distance 8 + compare/accumulate,
+    // SURVEY 8d), 64 for the prefilter (the 32 multiply-adds of the a_hi (b_hi + b_lo) expansion)
     double eval_pairs = 0.0;
     for (int p = 0; p < n_prob; ++p) {
       if (hp[p].done) continue;
@@ -1367,32 +1433,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                                       n_prob, s));
       ProfScope prof("ransac_eval", s, 30.0 * eval_pairs);
       hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                         dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                         dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
                          res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
-      const int ptiles = (b + PF_HYP - 1) / PF_HYP;
-      // 768 workgroups are resident (3 per CU): split the pair range until there are >= 8 rounds of
-      // workgroups, as long as a workgroup keeps >= 8 stages
-      int psplits = (int)((8 * 768 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
-      if (psplits < 1) psplits = 1;
-      if (psplits > 16) psplits = 16;
-      while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
-      hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, s, d_probs, hyp.p, pf_stat.p, it0, b, bmax, thr2, A16.p, c_h.p);
-      if (psplits > 1)
-        CS_HIP_CHECK(hipMemset2DAsync(cnt_up.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
-                                      n_prob, s));
-      {
-        // 64 FLOP per (hypothesis, pair): the 32 multiply-adds of the a_hi (b_hi + b_lo) expansion
-        ProfScope prof("ransac_pre", s, 64.0 * eval_pairs);
-        const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
-        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, s, d_probs, off16.p, B16.p,
-                           A16.p, c_h.p, it0, b, bmax, psplits, xcd_prob, pslots, ptiles, cnt_up.p,
-                           (trace_it0 == it0) ? trace.p : nullptr);
-        if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
-      }
+      prof_add_units("ransac_pre", 64.0 * eval_pairs);
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                         dim3(256), 0, s, d_probs, cnt_up.p, it0, b, bmax, res_cnt.p, cand_err.p, hlist.p,
+                         dim3(256), 0, s, d_probs, cnt_up_r, it0, b, bmax, res_cnt.p, cand_err.p, hlist.p,
                          d_nsurv);
       // exact counts of the survivors; few hypotheses, so the pair range is split finely
       int lsplits = 16;
@@ -1402,12 +1448,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         // the previous round's survivor counts pick the kernel (both are exact for any count)
         if (max_surv_prev <= 32) {
           hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob, 8), dim3(256), 0, s, d_probs, pk.p,
-                             tot1, hyp.p, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
+                             tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
           hipLaunchKernelGGL(k_ransac_count<true>, dim3((unsigned)(ltiles * lsplits), (unsigned)n_prob),
-                             dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, lsplits, thr2,
+                             dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, lsplits, thr2,
                              res_cnt.p, hlist.p, d_nsurv);
         }
       }
@@ -1415,10 +1461,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         CS_HIP_CHECK(hipMemset2DAsync(exact_dbg.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                       n_prob, s));
         hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp.p, it0, b, bmax, splits, thr2,
+                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
                            exact_dbg.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
         hipLaunchKernelGGL(k_ransac_check_bound, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
-                           dim3(256), 0, s, d_probs, exact_dbg.p, cnt_up.p, it0, b, bmax, chk_stats.p);
+                           dim3(256), 0, s, d_probs, exact_dbg.p, cnt_up_r, it0, b, bmax, chk_stats.p);
       }
     }
     static const hipError_t scan1_lds = hipFuncSetAttribute(
@@ -1428,9 +1474,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                        res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive);
     if (!err_known)
       hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
-                         tot1, hyp.p, bmax, cand.p, thr2, scale, cand_err.p);
+                         tot1, hyp_r, bmax, cand.p, thr2, scale, cand_err.p);
     hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       d_probs, n_prob, hyp.p, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax);
+                       d_probs, n_prob, hyp_r, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax);
     CS_LAUNCH_CHECK();
     // the per-problem state (est_k, done), the survivor counts and the activity counter come back in
     // one copy behind a synchronisation the chunk loop needs anyway
@@ -1438,15 +1484,20 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (pf) prev = hp;
     CS_HIP_CHECK(hipMemcpyAsync(h_state, state.p, st_bytes, hipMemcpyDeviceToHost, s));
     CS_HIP_CHECK(hipEventRecord(round_done.e, s));
-    // The next chunk's hypotheses do not depend on this round's outcome (finished problems skip
-    // themselves on the device), so they are generated while the host waits for the state and sizes the
-    // next round: the host turnaround disappears from the GPU timeline.
-    if (it0 + b < max_iter) {
-      const int it1 = it0 + b;
-      int b1 = it1 < 256 ? 256 : (it1 < bmax ? it1 : bmax);
-      if (b1 > max_iter - it1) b1 = max_iter - it1;
-      launch_hyp(it1, b1);
-      hyp_ready = true;
+    // front half of the next round: on the side stream once both rounds are prefiltered (before that
+    // the rounds are short and the exact count of round i+1 would compete with round i), else behind
+    // this round on the main stream
+    Front nxt;
+    const bool have_next = it0 + b < max_iter;
+    if (have_next) {
+      const bool nxt_pf = pf_alloc && it0 + b >= pf_from;
+      hipStream_t st = (side && pf && nxt_pf) ? side : s;
+      nxt = enqueue_front(it0 + b, cur.par ^ 1, st);
+      if (nxt.on_side) {
+        side_pending = true;
+        side_par = nxt.par;
+      }
+      CS_LAUNCH_CHECK();
     }
     CS_HIP_CHECK(hipEventSynchronize(round_done.e));
     memcpy(hp.data(), h_state, st_probs);
@@ -1461,9 +1512,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           if (h_surv[p] > max_surv_prev) max_surv_prev = h_surv[p];
         }
     }
-    it0 += b;
-    if (h_active == 0) break;
+    if (h_active == 0 || !have_next) break;
+    cur = nxt;
   }
+  // a speculative front half may still be running on the side stream (its workgroups see done = 1 and
+  // leave): the scratch buffers go back to the main stream's pool only behind it
+  if (side_pending) CS_HIP_CHECK(hipStreamWaitEvent(s, front_done[side_par].e, 0));
   if (trace_n) {
     std::vector<unsigned long long> ht(trace_n);
     CS_HIP_CHECK(hipMemcpy(ht.data(), trace.p, sizeof(unsigned long long) * trace_n, hipMemcpyDeviceToHost));

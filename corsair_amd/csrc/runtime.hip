@@ -195,6 +195,29 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), st
   (void)hipEventRecord(e0, stream);
 }
 
+void prof_add_units(const char* name, double units) {
+  if (!g_prof_on) return;
+  const int id = prof_id(name);
+  if (id < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_units[id] += units;
+}
+
+hipStream_t side_stream() {
+  thread_local hipStream_t st = nullptr;
+  thread_local int st_dev = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (dev != st_dev) {  // first use (or the thread moved to another device: the old stream is abandoned)
+    st_dev = dev;
+    st = nullptr;
+    int lo = 0, hi = 0;  // numerically greatest = lowest priority
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+  }
+  return st;
+}
+
 ProfScope::~ProfScope() {
   if (id < 0) return;
   (void)hipEventRecord(e1, stream);
