@@ -240,8 +240,9 @@ def main():
                     "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
                     "launches": d["launches"],
                     "flop_per_launch": d["flop"] / max(d["launches"], 1),
-                    "note": ("k_ransac_prefilter: 94 FLOP per (hypothesis, pair) = the 47 f16 multiply-adds of "
-                             "the hi/lo residual expansion, against the dense f16 MFMA peak; conv / "
+                    "note": ("k_ransac_prefilter: 64 FLOP per (hypothesis, pair) = the 32 f16 multiply-adds of "
+                             "the a_hi (b_hi + b_lo) residual expansion, against the dense f16 MFMA peak (the "
+                             "kernel's longer pipe is the VALU: one sign extraction per result); conv / "
                              "k_ransac_count are priced against the f32 matrix peak (157.3 TF), kNN / Chamfer "
                              "against the f64 matrix peak; see DESIGN.md")}
         # HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run of this same

@@ -1446,7 +1446,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       {
         ProfScope prof("ransac_eval", s);
         // the previous round's survivor counts pick the kernel (both are exact for any count)
-        if (max_surv_prev <= 32) {
+        if (max_surv_prev <= 128) {  // (32 / 64 / 128 / 256 measured: 128 is the fastest by ~1 %)
           hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob, 8), dim3(256), 0, s, d_probs, pk.p,
                              tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;

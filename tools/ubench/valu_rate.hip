@@ -7,6 +7,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr, unsigned long long* clk) {
   unsigned a = threadIdx.x, b = threadIdx.x * 3u, c = 5u, d = 7u;
   float f0 = (float)threadIdx.x, f1 = f0 * 0.5f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 p0 = {f0, f1}, p1 = {f1, f0}, p2 = {thr, thr};
   int cnt = 0;
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
@@ -42,6 +44,24 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr, un
       REP16(asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b));)
     } else if (MODE == 14) {  // alignbit with SGPR shift operand
       REP16(asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(31));)
+    } else if (MODE == 15) {  // packed f32 multiply with clamp (2 results per instruction)
+      REP16(asm volatile("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(p0) : "v"(p1), "v"(p2));)
+    } else if (MODE == 16) {  // packed f32 add, dependent
+      REP16(asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p0) : "v"(p1));)
+    } else if (MODE == 17) {  // v_med3_f32
+      REP16(asm volatile("v_med3_f32 %0, %0, %1, 0" : "+v"(f0) : "v"(f1));)
+    } else if (MODE == 18) {  // v_dot4c_i32_i8 accumulate
+      REP16(asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(cnt) : "v"(b), "v"(c));)
+    } else if (MODE == 19) {  // v_mul_f32 clamp (VOP3) independent
+      REP16(asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(f0) : "v"(f1), "v"(thr));)
+    } else if (MODE == 20) {  // v_pk_fma_f32 dependent
+      REP16(asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p0) : "v"(p1), "v"(p2));)
+    } else if (MODE == 21) {  // v_add_f32 dependent
+      REP16(asm volatile("v_add_f32 %0, %0, %1" : "+v"(f0) : "v"(f1));)
+    } else if (MODE == 22) {  // v_pk_add_u16
+      REP16(asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a) : "v"(b));)
+    } else if (MODE == 23) {  // v_subrev/ v_sub_u32 with ashr: two fast ops
+      REP16(asm volatile("v_ashrrev_i32 %1, 31, %2\n\tv_sub_u32 %0, %0, %1" : "+v"(a), "+v"(c) : "v"(b));)
     } else if (MODE == 9) {  // v_alignbit independent outputs (no chain), 16 distinct
       REP16(asm volatile("v_alignbit_b32 %0, %1, %2, 31" : "=v"(a) : "v"(b), "v"(c));)
     }
@@ -52,7 +72,7 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, float thr, un
     clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = c1 - c0;
     clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
   }
-  out[blockIdx.x * 256 + threadIdx.x] = a + c + d + cnt + (unsigned)f1 + (unsigned)f0;
+  out[blockIdx.x * 256 + threadIdx.x] = a + c + d + cnt + (unsigned)f1 + (unsigned)f0 + (unsigned)p0[0] + (unsigned)p0[1];
 }
 template <int MODE>
 void run(const char* name, int per_rep) {
@@ -99,5 +119,14 @@ int main() {
   run<12>("v_bcnt_u32_b32 accumulate", 1);
   run<13>("v_xor_b32 dependent", 1);
   run<14>("alignbit, sgpr shift", 1);
+  run<15>("v_pk_mul_f32 clamp", 1);
+  run<16>("v_pk_add_f32 dependent", 1);
+  run<20>("v_pk_fma_f32 dependent", 1);
+  run<17>("v_med3_f32 dependent", 1);
+  run<18>("v_dot4c_i32_i8 accumulate", 1);
+  run<19>("v_mul_f32 clamp (VOP3)", 1);
+  run<21>("v_add_f32 dependent", 1);
+  run<22>("v_pk_add_u16 dependent", 1);
+  run<23>("v_ashrrev + v_sub_u32", 2);
   return 0;
 }
