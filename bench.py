@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--catalog", type=int, default=N_CATALOG)
     ap.add_argument("--pipeline", type=int, default=1,
                     help="query batches in flight in the timed region (host threads x HIP streams)")
+    ap.add_argument("--no-solo-probe", action="store_true",
+                    help="skip the extra pass that times the dominant kernel without concurrent work")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra two-batches-in-flight pass reported as `two_batches_in_flight`")
     return ap.parse_args()
@@ -182,6 +184,37 @@ def main():
     elapsed = time.time() - t_start
     _lib.prof_enable(False)
     log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
+    fam = {}
+    for name in ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap"):
+        ms, n, units = _lib.prof_get(name)
+        fam[name] = {"ms": ms, "launches": n, "flop": units}
+    # In the timed region the prefilter launches of a step overlap other work (the vanilla and the
+    # symmetric RANSAC calls run on two host threads, the small kernels of a round run under the next
+    # prefilter), so their event-bracketed durations include the share of the GPU they did not have.
+    # A short extra pass with both overlaps switched off gives the kernel's stand-alone rate (same inputs,
+    # same launches merged back into one call); reported as roofline.solo, not used for `value`.
+    solo = None
+    if world == 1 and not args.no_solo_probe and args.steps >= 1:
+        saved = {k: os.environ.get(k) for k in ("CS_RANSAC_OVERLAP", "CORSAIR_SPLIT_RANSAC")}
+        os.environ["CS_RANSAC_OVERLAP"] = "0"
+        os.environ["CORSAIR_SPLIT_RANSAC"] = "0"
+        try:
+            keep = list(results)
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            run_steps(args.warmup, args.warmup + min(2, args.steps), depth=1)
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
+            ms, n, units = _lib.prof_get("ransac_pre")
+            solo = {"ms": ms, "launches": n, "flop": units}
+            results[:] = keep
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        log("stand-alone prefilter pass done")
     # Throughput mode, reported next to the contract number (never instead of it): the same K batches
     # again with two of them in flight.  Kernels of the two streams share the GPU, so per-launch event
     # times are not a roofline measurement there; profiling stays off.  The poses must come out
@@ -223,11 +256,6 @@ def main():
     iters_all = np.concatenate(iters_all)
 
     if rank == 0:
-        fam = {}
-        for name in ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut",
-                     "kmap"):
-            ms, n, units = _lib.prof_get(name)
-            fam[name] = {"ms": ms, "launches": n, "flop": units}
         dom = max(("conv", "ransac_eval", "ransac_pre", "knn", "chamfer"), key=lambda k: fam[k]["ms"])
         d = fam[dom]
         peak = {"knn": F64_PEAK_TFLOPS, "chamfer": F64_PEAK_TFLOPS, "ransac_pre": F16_PEAK_TFLOPS}.get(
@@ -240,11 +268,18 @@ def main():
                     "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
                     "launches": d["launches"],
                     "flop_per_launch": d["flop"] / max(d["launches"], 1),
+                    "concurrent": True,
                     "note": ("k_ransac_prefilter: 64 FLOP per (hypothesis, pair) = the 32 f16 multiply-adds of "
                              "the a_hi (b_hi + b_lo) residual expansion, against the dense f16 MFMA peak (the "
                              "kernel's longer pipe is the VALU: one sign extraction per result); conv / "
                              "k_ransac_count are priced against the f32 matrix peak (157.3 TF), kNN / Chamfer "
                              "against the f64 matrix peak; see DESIGN.md")}
+        if solo and dom == "ransac_pre" and solo["launches"]:
+            a_solo = solo["flop"] / (solo["ms"] * 1e-3) / 1e12
+            roofline["solo"] = {"achieved": a_solo, "frac": a_solo / peak,
+                                "avg_launch_ms": solo["ms"] / solo["launches"], "launches": solo["launches"],
+                                "note": "same kernel and inputs with CS_RANSAC_OVERLAP=0 CORSAIR_SPLIT_RANSAC=0 "
+                                        "(nothing else on the GPU while it runs), extra untimed pass"}
         # HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run of this same
         # command (FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

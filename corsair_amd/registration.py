@@ -17,6 +17,9 @@ torch is used for index plumbing on the device (stable sort of part labels, gath
 """
 from __future__ import annotations
 
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
@@ -26,6 +29,28 @@ from . import backend as B
 from ._lib import to_host
 
 ANCHOR_KEY = 0x5A11C0DE
+
+# The vanilla RANSACs of a batch need nothing from the symmetry stages: they run on a helper thread
+# with its own stream while the calling thread goes through part cut, host gate and labelled 5-NN (a
+# launch sequence with two host decisions in it, during which the GPU would otherwise idle), then the
+# symmetric hypotheses get their own cs_ransac_batch call.  The draws of a problem depend on (seed,
+# iteration) only, so splitting the call changes no result.  CORSAIR_SPLIT_RANSAC=0 keeps one call.
+_tls = threading.local()
+
+
+def _helper():
+    if getattr(_tls, "pool", None) is None:
+        _tls.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="corsair-ransac")
+        _tls.stream = {}
+    return _tls.pool
+
+
+def _helper_stream(dev):
+    _helper()
+    if dev not in _tls.stream:
+        _tls.stream[dev] = torch.cuda.Stream(device=dev)
+    return _tls.stream[dev]
+
 
 
 @dataclass
@@ -152,94 +177,130 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
     prob_len = [n0[p] * k for p in range(P)]
     prob_pair = list(range(P))
     ok = np.zeros(P, dtype=bool)
+    vanilla = None
+    if use_symmetry and dev.type == "cuda" and os.environ.get("CORSAIR_SPLIT_RANSAC", "1") != "0":
+        v_src, v_tgt = xyz0[src_rows], xyz1[tgt_rows]
+        v_offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
+        ready = torch.cuda.current_stream(dev).record_event()
+        side = _helper_stream(dev)
+        for t in (v_src, v_tgt):
+            t.record_stream(side)
 
-    # ---- 2./3. symmetry hypotheses ---------------------------------------------------------------
-    if use_symmetry:
-        Ks = [4 if int(pos_syms[p]) >= 2 else 2 for p in range(P)]
-        if anchor_ids is None:
-            anchor_ids = [(2 * p, 2 * p + 1) for p in range(P)]
-        anc0 = query_anchors if query_anchors is not None else \
-            [draw_anchors(n0[p], n_anchor, anchor_ids[p][0]) for p in range(P)]
-        anc1 = [draw_anchors(n1[p], n_anchor, anchor_ids[p][1]) for p in range(P)]
-        cand = [p for p in range(P) if anc0[p] is not None and anc1[p] is not None]
-        sel0 = np.zeros((P, 4, 3))
-        sel1 = np.zeros((P, 4, 3))
-        if cand:
-            # one launch set for both sides (query clouds, then CAD clouds): the k-means stage is
-            # latency-bound (one thread per restart), twice the clouds cost the same time
-            def anchors_of(anc):
-                return np.stack([anc[p] if anc[p] is not None else np.zeros(n_anchor, np.int32) for p in range(P)])
+        def run_vanilla():
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                return B.ransac_batch(v_src, v_tgt, v_offs, max_corr, 10, max_iter, confidence, seed)
 
-            a_all = torch.from_numpy(np.concatenate([anchors_of(anc0), anchors_of(anc1)])).to(dev)
-            off_all = off0 + [off0[-1] + o for o in off1[1:]]
-            c, cnt, mcd, mer = B.symcut_fit(torch.cat([baseF, posF]), torch.cat([xyz0, xyz1]), off_all, a_all,
-                                            Ks + Ks, 50, 10, 300, 0)
-            c, cnt, mcd, mer = to_host(c, cnt, mcd, mer)
-            c0, cnt0, mcd0, mer0 = c[:P], cnt[:P], mcd[:P], mer[:P]
-            c1, cnt1, mcd1, mer1 = c[P:], cnt[P:], mcd[P:], mer[P:]
-            g0, ok0 = gate_and_order_batch(c0, cnt0, mcd0, mer0, n0, Ks, cand, force_gate)
-            g1, ok1 = gate_and_order_batch(c1, cnt1, mcd1, mer1, n1, Ks, cand, force_gate)
-            ok = ok0 & ok1
-            sel0[ok], sel1[ok] = g0[ok], g1[ok]
-        good = [p for p in range(P) if ok[p]]
-        if good:
-            lab0 = B.symcut_labels(xyz0, off0, Ks, torch.from_numpy(sel0).to(dev))
-            lab1 = B.symcut_labels(xyz1, off1, Ks, torch.from_numpy(sel1).to(dev))
-            qseg, tseg, perms, cfg_pair = [], [], [], []
-            for p in good:
-                for cfg in part_configs(Ks[p], int(pos_syms[p])):
-                    qseg.append(p)
-                    tseg.append(p)
-                    perms.append(cfg + [-3] * (8 - len(cfg)))
-                    cfg_pair.append(p)
-            perm_t = torch.tensor(perms, dtype=torch.int32, device=dev)
-            # stable partition of every query cloud by part label (split_corr concatenates the parts
-            # in order, rows in original order inside a part): one stable sort of (pair, label) keys.
-            # The labelled search runs on the partitioned rows, so a wave of 64 queries shares one
-            # label and skips the targets of the other parts wholesale.
-            seg_rows = torch.repeat_interleave(torch.arange(P, device=dev, dtype=torch.int64),
-                                               torch.tensor(n0, device=dev, dtype=torch.int64),
-                                               output_size=off0[-1])
-            sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
-            nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
-                                qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
-            # Assemble the correspondences of every configuration with a handful of device ops (no
-            # per-configuration launch or host round trip): configuration j owns the query rows
-            # sorted_rows[off0[p] : off0[p+1]] and the result rows nn_cfg[row_j : row_j + n0[p]].
-            lens = np.asarray([n0[p] for p in cfg_pair], dtype=np.int64)
-            row_start = np.concatenate([[0], np.cumsum(lens)])
-            # a CAD part with fewer than k voxels leaves -1 entries: the reference cannot build that
-            # configuration (one reduction + one small copy decides all of them)
-            neg = torch.cumsum((nn_cfg < 0).any(dim=1).to(torch.int32), 0)
-            neg = torch.cat([neg.new_zeros(1), neg])
-            ends = torch.from_numpy(row_start).to(dev)
-            bad = to_host(neg[ends[1:]] - neg[ends[:-1]])[0] > 0
-            keep = [j for j in range(len(cfg_pair)) if not bad[j]]
-            if keep:
-                L = torch.from_numpy(lens[keep]).to(dev)
-                total = int(lens[keep].sum())
-                seg_first = torch.cumsum(L, 0) - L
-                base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(
-                    seg_first, L, output_size=total)
-                q_first = torch.tensor([off0[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
-                n_first = torch.from_numpy(row_start[:-1][keep]).to(dev)
-                t_first = torch.tensor([off1[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
-                q_rows = torch.repeat_interleave(q_first, L, output_size=total) + base
-                n_rows = torch.repeat_interleave(n_first, L, output_size=total) + base
-                prob_src.append(sorted_rows[q_rows].repeat_interleave(k))
-                prob_tgt.append((nn_cfg[n_rows].to(torch.int64)
-                                 + torch.repeat_interleave(t_first, L, output_size=total)[:, None]).reshape(-1))
-                for j in keep:
-                    prob_len.append(n0[cfg_pair[j]] * k)
-                    prob_pair.append(cfg_pair[j])
+        vanilla = _helper().submit(run_vanilla)
+
+    try:
+        # ---- 2./3. symmetry hypotheses ---------------------------------------------------------------
+        if use_symmetry:
+            Ks = [4 if int(pos_syms[p]) >= 2 else 2 for p in range(P)]
+            if anchor_ids is None:
+                anchor_ids = [(2 * p, 2 * p + 1) for p in range(P)]
+            anc0 = query_anchors if query_anchors is not None else \
+                [draw_anchors(n0[p], n_anchor, anchor_ids[p][0]) for p in range(P)]
+            anc1 = [draw_anchors(n1[p], n_anchor, anchor_ids[p][1]) for p in range(P)]
+            cand = [p for p in range(P) if anc0[p] is not None and anc1[p] is not None]
+            sel0 = np.zeros((P, 4, 3))
+            sel1 = np.zeros((P, 4, 3))
+            if cand:
+                # one launch set for both sides (query clouds, then CAD clouds): the k-means stage is
+                # latency-bound (one thread per restart), twice the clouds cost the same time
+                def anchors_of(anc):
+                    return np.stack([anc[p] if anc[p] is not None else np.zeros(n_anchor, np.int32) for p in range(P)])
+
+                a_all = torch.from_numpy(np.concatenate([anchors_of(anc0), anchors_of(anc1)])).to(dev)
+                off_all = off0 + [off0[-1] + o for o in off1[1:]]
+                c, cnt, mcd, mer = B.symcut_fit(torch.cat([baseF, posF]), torch.cat([xyz0, xyz1]), off_all, a_all,
+                                                Ks + Ks, 50, 10, 300, 0)
+                c, cnt, mcd, mer = to_host(c, cnt, mcd, mer)
+                c0, cnt0, mcd0, mer0 = c[:P], cnt[:P], mcd[:P], mer[:P]
+                c1, cnt1, mcd1, mer1 = c[P:], cnt[P:], mcd[P:], mer[P:]
+                g0, ok0 = gate_and_order_batch(c0, cnt0, mcd0, mer0, n0, Ks, cand, force_gate)
+                g1, ok1 = gate_and_order_batch(c1, cnt1, mcd1, mer1, n1, Ks, cand, force_gate)
+                ok = ok0 & ok1
+                sel0[ok], sel1[ok] = g0[ok], g1[ok]
+            good = [p for p in range(P) if ok[p]]
+            if good:
+                lab0 = B.symcut_labels(xyz0, off0, Ks, torch.from_numpy(sel0).to(dev))
+                lab1 = B.symcut_labels(xyz1, off1, Ks, torch.from_numpy(sel1).to(dev))
+                qseg, tseg, perms, cfg_pair = [], [], [], []
+                for p in good:
+                    for cfg in part_configs(Ks[p], int(pos_syms[p])):
+                        qseg.append(p)
+                        tseg.append(p)
+                        perms.append(cfg + [-3] * (8 - len(cfg)))
+                        cfg_pair.append(p)
+                perm_t = torch.tensor(perms, dtype=torch.int32, device=dev)
+                # stable partition of every query cloud by part label (split_corr concatenates the parts
+                # in order, rows in original order inside a part): one stable sort of (pair, label) keys.
+                # The labelled search runs on the partitioned rows, so a wave of 64 queries shares one
+                # label and skips the targets of the other parts wholesale.
+                seg_rows = torch.repeat_interleave(torch.arange(P, device=dev, dtype=torch.int64),
+                                                   torch.tensor(n0, device=dev, dtype=torch.int64),
+                                                   output_size=off0[-1])
+                sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
+                nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
+                                    qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
+                # Assemble the correspondences of every configuration with a handful of device ops (no
+                # per-configuration launch or host round trip): configuration j owns the query rows
+                # sorted_rows[off0[p] : off0[p+1]] and the result rows nn_cfg[row_j : row_j + n0[p]].
+                lens = np.asarray([n0[p] for p in cfg_pair], dtype=np.int64)
+                row_start = np.concatenate([[0], np.cumsum(lens)])
+                # a CAD part with fewer than k voxels leaves -1 entries: the reference cannot build that
+                # configuration (one reduction + one small copy decides all of them)
+                neg = torch.cumsum((nn_cfg < 0).any(dim=1).to(torch.int32), 0)
+                neg = torch.cat([neg.new_zeros(1), neg])
+                ends = torch.from_numpy(row_start).to(dev)
+                bad = to_host(neg[ends[1:]] - neg[ends[:-1]])[0] > 0
+                keep = [j for j in range(len(cfg_pair)) if not bad[j]]
+                if keep:
+                    L = torch.from_numpy(lens[keep]).to(dev)
+                    total = int(lens[keep].sum())
+                    seg_first = torch.cumsum(L, 0) - L
+                    base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(
+                        seg_first, L, output_size=total)
+                    q_first = torch.tensor([off0[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
+                    n_first = torch.from_numpy(row_start[:-1][keep]).to(dev)
+                    t_first = torch.tensor([off1[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
+                    q_rows = torch.repeat_interleave(q_first, L, output_size=total) + base
+                    n_rows = torch.repeat_interleave(n_first, L, output_size=total) + base
+                    prob_src.append(sorted_rows[q_rows].repeat_interleave(k))
+                    prob_tgt.append((nn_cfg[n_rows].to(torch.int64)
+                                     + torch.repeat_interleave(t_first, L, output_size=total)[:, None]).reshape(-1))
+                    for j in keep:
+                        prob_len.append(n0[cfg_pair[j]] * k)
+                        prob_pair.append(cfg_pair[j])
+    except BaseException:
+        if vanilla is not None:       # do not leave the helper's call running into freed tensors
+            try:
+                vanilla.result()
+            except Exception:
+                pass
+        raise
 
     # ---- 4. RANSAC over all hypotheses (registration_based_on_corr, utils/eval_pose.py:82-100) ----
-    src_idx = torch.cat(prob_src)
-    tgt_idx = torch.cat(prob_tgt)
-    src_pts = xyz0[src_idx]
-    tgt_pts = xyz1[tgt_idx]
-    offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
-    T, inl, rmse, iters = B.ransac_batch(src_pts, tgt_pts, offs, max_corr, 10, max_iter, confidence, seed)
+    if vanilla is None:
+        src_idx = torch.cat(prob_src)
+        tgt_idx = torch.cat(prob_tgt)
+        offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
+        T, inl, rmse, iters = B.ransac_batch(xyz0[src_idx], xyz1[tgt_idx], offs, max_corr, 10, max_iter,
+                                             confidence, seed)
+    else:
+        parts = []
+        if len(prob_src) > 1:
+            src_idx = torch.cat(prob_src[1:])
+            tgt_idx = torch.cat(prob_tgt[1:])
+            offs = np.concatenate([[0], np.cumsum(prob_len[P:])]).tolist()
+            parts = [B.ransac_batch(xyz0[src_idx], xyz1[tgt_idx], offs, max_corr, 10, max_iter, confidence, seed)]
+        first = vanilla.result()              # cs_ransac_batch returns with its stream drained
+        cur = torch.cuda.current_stream(dev)
+        for t in first:
+            t.record_stream(cur)
+        T, inl, rmse, iters = (torch.cat([a] + [q[i] for q in parts]) for i, a in enumerate(first))
 
     # ---- 5. Chamfer of every estimate (utils/preprocess.py:39-48,67-70) -----------------------------
     cd = B.chamfer_1dir(xyz0, off0, xyz1, off1, prob_pair, prob_pair, T)
