@@ -108,9 +108,16 @@ class KernelMap:
         lib = _lib.load()
         self.n_out = int(lib.cs_kernelmap_rows(self._h))
         self.n_in = in_map.n
-        self.num_pairs = int(lib.cs_kernelmap_num_pairs(self._h))
+        self._num_pairs = None
         self.transposed = transposed
         self.device = in_map.device
+
+    @property
+    def num_pairs(self):
+        """Resolved on first use: building a map does not wait for its pair count."""
+        if self._num_pairs is None:
+            self._num_pairs = int(_lib.load().cs_kernelmap_num_pairs(self._h))
+        return self._num_pairs
 
     @classmethod
     def build(cls, in_map, out_map, kernel_size=3, transposed=False):

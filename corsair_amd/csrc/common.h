@@ -127,5 +127,14 @@ struct cs_kernelmap {
   int transposed = 0;
   int32_t* d_nbr = nullptr;      // [n_out, kvol]
   int32_t* d_rowlist = nullptr;  // [n_out] output rows ordered by neighbour-presence mask (tiling order)
+  // Pair count: written by the build kernels, copied to a page-locked slot behind them; resolved on
+  // first use (kernelmap_pairs) so that building a map does not stall the host.
   int64_t num_pairs = -1;
+  hipEvent_t cnt_ready = nullptr;
+  unsigned long long* h_cnt = nullptr;
+  int cnt_slot = -1;
 };
+namespace cs {
+int64_t kernelmap_pairs(const cs_kernelmap* km);
+bool prof_enabled();
+}

@@ -316,7 +316,8 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   }
   if (n_out == 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
-  const double flop = 2.0 * (double)(km ? km->num_pairs : n_out) * (double)cin * (double)cout;
+  // (the pair count of a freshly built map is resolved here only when profiling is on)
+  const double flop = prof_enabled() ? 2.0 * (double)(km ? kernelmap_pairs(km) : n_out) * (double)cin * (double)cout : 0.0;
   ProfScope prof("conv", s, flop);
   const bool mfma_ok = (cin % 32 == 0) && (cout % 4 == 0) && (ld_in % 4 == 0) &&
                        aligned16(d_in) && aligned16(d_w);

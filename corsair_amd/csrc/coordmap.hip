@@ -12,6 +12,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -140,6 +141,36 @@ __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_ou
   // wave-level count then one atomic per wave
   unsigned long long m = __ballot(found);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
+}
+
+// The same probes for the samples the LDS kernel flagged (too many voxels / too wide), launched behind
+// it without a host decision: grid (slices, samples), a workgroup of an unflagged sample leaves at once.
+__global__ __launch_bounds__(256) void k_build_nbr_flagged(
+    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int step, int sign,
+    const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, uint64_t mask,
+    int32_t* __restrict__ nbr, unsigned long long* pair_count, const int* __restrict__ flagged) {
+  const int b = blockIdx.y;
+  if (!flagged[b]) return;
+  const int64_t t0 = (int64_t)out_seg[b] * 27, t1 = (int64_t)out_seg[b + 1] * 27;
+  for (int64_t base = t0 + (int64_t)blockIdx.x * 256; base < t1; base += (int64_t)gridDim.x * 256) {
+    const int64_t t = base + threadIdx.x;
+    int found = 0;
+    if (t < t1) {
+      const int64_t o = t / 27;
+      const int k = (int)(t - o * 27);
+      const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+      const int bb = out_coords[4 * o + 0];
+      const int x = out_coords[4 * o + 1] + sign * dx * step;
+      const int y = out_coords[4 * o + 2] + sign * dy * step;
+      const int z = out_coords[4 * o + 3] + sign * dz * step;
+      int32_t v = -1;
+      if (coord_in_range(bb, x, y, z)) v = hash_lookup(keys, vals, mask, pack_key(bb, x, y, z));
+      nbr[t] = v;
+      found = v >= 0;
+    }
+    const unsigned long long m = __ballot(found);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,6 +346,46 @@ static int ensure_segments(cs_coordmap* m, hipStream_t s) {
   m->max_seg = h_flags[1];
   m->seg_state = 1;
   return CS_OK;
+}
+
+// Page-locked slots for the pair counts of kernel maps (one per live map, recycled on free).
+namespace {
+std::mutex g_slot_mu;
+std::vector<unsigned long long*> g_slot_slabs;
+std::vector<int> g_slot_free;
+constexpr int SLOTS_PER_SLAB = 1024;
+}  // namespace
+
+static unsigned long long* count_slot_acquire(int* slot) {
+  std::lock_guard<std::mutex> lk(g_slot_mu);
+  if (g_slot_free.empty()) {
+    unsigned long long* slab = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&slab), sizeof(unsigned long long) * SLOTS_PER_SLAB, 0) !=
+        hipSuccess)
+      return nullptr;
+    const int first = (int)g_slot_slabs.size() * SLOTS_PER_SLAB;
+    g_slot_slabs.push_back(slab);
+    for (int i = SLOTS_PER_SLAB - 1; i >= 0; --i) g_slot_free.push_back(first + i);
+  }
+  *slot = g_slot_free.back();
+  g_slot_free.pop_back();
+  return g_slot_slabs[*slot / SLOTS_PER_SLAB] + *slot % SLOTS_PER_SLAB;
+}
+
+static void count_slot_release(int slot) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_slot_mu);
+  g_slot_free.push_back(slot);
+}
+
+int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
+  cs_kernelmap* km = const_cast<cs_kernelmap*>(km_c);  // cached on first use
+  if (!km) return -1;
+  if (km->num_pairs < 0 && km->cnt_ready && km->h_cnt) {
+    if (hipEventSynchronize(km->cnt_ready) != hipSuccess) return -1;
+    km->num_pairs = (int64_t)*km->h_cnt;
+  }
+  return km->num_pairs;
 }
 
 // Tiling order of the convolution kernels: rows grouped by the top ROWKEY_BITS bits of their 27-bit
@@ -654,23 +725,21 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     set_error("cs_kernelmap_build: allocation failed");
     return CS_ERR_HIP;
   }
-  unsigned long long h_cnt = 0;
   hipError_t e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s);
-  // LDS path: per-sample hash tables (see k_build_nbr_lds); otherwise the global table
-  bool used_lds = false, need_global = false;
+  // LDS path: per-sample hash tables (see k_build_nbr_lds), the flagged samples through the global
+  // table right behind it; otherwise the global table for everything.  No host decision in between:
+  // the pair count travels to a page-locked slot and is read when somebody asks (kernelmap_pairs).
+  bool used_lds = false;
   PoolBuf<int> fb;
-  unsigned long long* lds_cnt = nullptr;  // counter / flags written by the LDS path
-  int* lds_fb = nullptr;
+  const unsigned long long* d_cnt = cnt.p;
   if (e == hipSuccess && total > 0 && km->kvol == 27 && getenv("CS_KMAP_GLOBAL") == nullptr) {
     cs_coordmap* in_m = const_cast<cs_coordmap*>(in);
     cs_coordmap* out_m = const_cast<cs_coordmap*>(out);
     if (ensure_segments(in_m, s) == CS_OK && ensure_segments(out_m, s) == CS_OK &&
-        in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch &&
-        true) {
+        in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch) {
       const int nb = in_m->n_batch;
-      // pair counter and per-sample fallback flags in one block: one memset, one copy back
+      // pair counter and per-sample fallback flags in one block: one memset
       fb.alloc(2 + nb);
-      std::vector<int> h_st(2 + nb, 0);
       if (fb.p) {
         unsigned long long* const cnt_p = reinterpret_cast<unsigned long long*>(fb.p);
         int* const fb_p = fb.p + 2;
@@ -682,37 +751,42 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
           hipLaunchKernelGGL(k_build_nbr_lds, dim3((unsigned)slices, (unsigned)nb), dim3(1024), 0, s,
                              in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
                              in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+          hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, out->d_coords,
+                             out_m->d_seg, step, sign, in->d_keys, in->d_vals, in->capacity - 1,
+                             km->d_nbr, cnt_p, fb_p);
           e = hipGetLastError();
         }
-        if (e == hipSuccess)
-          e = download_async(h_st.data(), fb.p, sizeof(int) * (2 + nb), s);
-        if (e == hipSuccess) e = download_sync(s);
         if (e == hipSuccess) {
           used_lds = true;
-          memcpy(&h_cnt, h_st.data(), sizeof(h_cnt));
-          for (int b = 0; b < nb; ++b) need_global = need_global || h_st[2 + b] != 0;
-          lds_cnt = cnt_p;
-          lds_fb = fb_p;
+          d_cnt = cnt_p;
         }
       }
     }
   }
-  if (e == hipSuccess && total > 0 && (!used_lds || need_global)) {
+  if (e == hipSuccess && total > 0 && !used_lds) {
     hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        out->d_coords, km->n_out, km->kvol, step, sign, in->d_keys, in->d_vals,
-                       in->capacity - 1, km->d_nbr, used_lds ? lds_cnt : cnt.p,
-                       used_lds ? lds_fb : (const int*)nullptr);
+                       in->capacity - 1, km->d_nbr, cnt.p, (const int*)nullptr);
     e = hipGetLastError();
-    if (e == hipSuccess)
-      e = download_async(&h_cnt, used_lds ? lds_cnt : cnt.p, sizeof(h_cnt), s);
-    if (e == hipSuccess) e = download_sync(s);
+  }
+  if (e == hipSuccess) {
+    if (total == 0) {
+      km->num_pairs = 0;
+    } else {
+      km->h_cnt = count_slot_acquire(&km->cnt_slot);
+      if (!km->h_cnt || hipEventCreateWithFlags(&km->cnt_ready, hipEventDisableTiming) != hipSuccess) {
+        e = hipErrorOutOfMemory;
+      } else {
+        e = hipMemcpyAsync(km->h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(km->cnt_ready, s);
+      }
+    }
   }
   if (e != hipSuccess) {
     cs_kernelmap_free(km);
     set_error("cs_kernelmap_build: %s", hipGetErrorString(e));
     return CS_ERR_HIP;
   }
-  km->num_pairs = (int64_t)h_cnt;
   // tiling order for the convolution kernels: rows grouped by presence-mask key (k_row_keys)
   if (km->kvol == 27 && km->n_out > 0) {
     const int64_t n = km->n_out;
@@ -742,16 +816,16 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
   return CS_OK;
 }
 
-int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km) { return km ? km->num_pairs : -1; }
+int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km) { return cs::kernelmap_pairs(km); }
 int64_t cs_kernelmap_rows(const cs_kernelmap* km) { return km ? km->n_out : -1; }
 const int32_t* cs_kernelmap_table(const cs_kernelmap* km) { return km ? km->d_nbr : nullptr; }
 
 int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in, int32_t* d_out,
                             int64_t capacity, void* stream) {
   CS_REQUIRE(km && d_k && d_in && d_out, CS_ERR_INVALID, "cs_kernelmap_export: NULL argument");
-  CS_REQUIRE(capacity >= km->num_pairs, CS_ERR_INVALID,
-             "cs_kernelmap_export: capacity %lld < %lld pairs", (long long)capacity,
-             (long long)km->num_pairs);
+  const int64_t pairs = cs::kernelmap_pairs(km);
+  CS_REQUIRE(pairs >= 0 && capacity >= pairs, CS_ERR_INVALID,
+             "cs_kernelmap_export: capacity %lld < %lld pairs", (long long)capacity, (long long)pairs);
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
   const int64_t total = km->n_out * km->kvol;
@@ -769,13 +843,18 @@ int64_t cs_kernelmap_export(const cs_kernelmap* km, int32_t* d_k, int32_t* d_in,
                      flag.p, pos.p, capacity, d_k, d_in, d_out);
   CS_LAUNCH_CHECK();
   CS_HIP_CHECK(download_sync(s));
-  return km->num_pairs;
+  return pairs;
 }
 
 void cs_kernelmap_free(cs_kernelmap* km) {
   if (!km) return;
   pool_free(km->d_nbr);
   pool_free(km->d_rowlist);
+  if (km->cnt_ready) {
+    (void)hipEventSynchronize(km->cnt_ready);  // the slot must not be recycled under a pending copy
+    (void)hipEventDestroy(km->cnt_ready);
+  }
+  count_slot_release(km->cnt_slot);
   delete km;
 }
 

@@ -195,6 +195,8 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), st
   (void)hipEventRecord(e0, stream);
 }
 
+bool prof_enabled() { return g_prof_on != 0; }
+
 void prof_add_units(const char* name, double units) {
   if (!g_prof_on) return;
   const int id = prof_id(name);

@@ -80,6 +80,8 @@ void cs_coordmap_free(cs_coordmap* m);
  * ---------------------------------------------------------------------------------------- */
 int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size,
                        int transposed, void* stream, cs_kernelmap** km);
+/* cs_kernelmap_build only enqueues work on `stream`; the pair count reaches the host behind it and
+ * cs_kernelmap_num_pairs waits for that copy the first time it is asked (then it is cached). */
 int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km);
 int64_t cs_kernelmap_rows(const cs_kernelmap* km);
 const int32_t* cs_kernelmap_table(const cs_kernelmap* km);
