@@ -18,39 +18,22 @@ torch is used for index plumbing on the device (stable sort of part labels, gath
 from __future__ import annotations
 
 import os
-import threading
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
+from . import _helper
 from . import backend as B
 from ._lib import to_host
 
 ANCHOR_KEY = 0x5A11C0DE
 
-# The vanilla RANSACs of a batch need nothing from the symmetry stages: they run on a helper thread
-# with its own stream while the calling thread goes through part cut, host gate and labelled 5-NN (a
-# launch sequence with two host decisions in it, during which the GPU would otherwise idle), then the
-# symmetric hypotheses get their own cs_ransac_batch call.  The draws of a problem depend on (seed,
+# The vanilla RANSACs of a batch need nothing from the symmetry stages: they run on the helper thread
+# (_helper.py) with its own stream while the calling thread goes through part cut, host gate and labelled
+# 5-NN (a launch sequence with two host decisions in it, during which the GPU would otherwise idle), then
+# the symmetric hypotheses get their own cs_ransac_batch call.  The draws of a problem depend on (seed,
 # iteration) only, so splitting the call changes no result.  CORSAIR_SPLIT_RANSAC=0 keeps one call.
-_tls = threading.local()
-
-
-def _helper():
-    if getattr(_tls, "pool", None) is None:
-        _tls.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="corsair-ransac")
-        _tls.stream = {}
-    return _tls.pool
-
-
-def _helper_stream(dev):
-    _helper()
-    if dev not in _tls.stream:
-        _tls.stream[dev] = torch.cuda.Stream(device=dev)
-    return _tls.stream[dev]
-
 
 
 @dataclass
@@ -181,18 +164,10 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
     if use_symmetry and dev.type == "cuda" and os.environ.get("CORSAIR_SPLIT_RANSAC", "1") != "0":
         v_src, v_tgt = xyz0[src_rows], xyz1[tgt_rows]
         v_offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
-        ready = torch.cuda.current_stream(dev).record_event()
-        side = _helper_stream(dev)
         for t in (v_src, v_tgt):
-            t.record_stream(side)
-
-        def run_vanilla():
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                return B.ransac_batch(v_src, v_tgt, v_offs, max_corr, 10, max_iter, confidence, seed)
-
-        vanilla = _helper().submit(run_vanilla)
+            t.record_stream(_helper.stream(dev))
+        vanilla = _helper.submit(dev, lambda: B.ransac_batch(v_src, v_tgt, v_offs, max_corr, 10, max_iter,
+                                                            confidence, seed))
 
     try:
         # ---- 2./3. symmetry hypotheses ---------------------------------------------------------------
