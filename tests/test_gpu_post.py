@@ -302,6 +302,36 @@ def test_sym_pose_matches_oracle(gpu, oracle_native):
         assert float(res.cd_best[p]) <= float(res.cd_ransac[p])  # invariant of the caches
 
 
+def test_sym_pose_is_independent_of_the_overlap_switches(gpu, monkeypatch):
+    """The vanilla / symmetric split of the RANSAC call (helper thread + stream) and the pipelined RANSAC
+    rounds (second stream inside cs_ransac_batch) only change WHEN work runs: every output is identical
+    to the single-call, single-stream path.  force_gate keeps the symmetric hypotheses in play and
+    max_iter spans prefiltered, pipelined rounds."""
+    from corsair_amd import registration as R
+
+    F, X, off = _engine_features(gpu, [30, 31, 32, 30, 31, 32], [7, 8, 9, None, None, None])
+    off0, off1 = off[:4], [o - off[3] for o in off[3:]]
+    bF, x0 = F[:off[3]].contiguous(), X[:off[3]].contiguous()
+    pF, x1 = F[off[3]:].contiguous(), X[off[3]:].contiguous()
+
+    def run():
+        r = R.sym_pose_batch(bF, x0, off0, pF, x1, off1, [1, 2, 4], 5, 0.2, 0, None, 100, 40000, 0.999,
+                             force_gate=True)
+        return [t.cpu().numpy() for t in (r.T_best, r.cd_best, r.T_ransac, r.cd_ransac, r.iters)] + [r.ok]
+
+    monkeypatch.setenv("CORSAIR_SPLIT_RANSAC", "0")
+    monkeypatch.setenv("CS_RANSAC_OVERLAP", "0")
+    want = run()
+    assert want[4].max() > 16384                         # several prefiltered rounds were run
+    for split, overlap in (("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("CORSAIR_SPLIT_RANSAC", split)
+        monkeypatch.setenv("CS_RANSAC_OVERLAP", overlap)
+        for _ in range(2):                               # timing-dependent paths: twice each
+            got = run()
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b), (split, overlap)
+
+
 @pytest.mark.parametrize("nq,nx,d,k", [(37, 5000, 256, 10), (5, 70, 256, 3), (300, 9000, 512, 1),
                                        (130, 20000, 100, 10)])
 def test_l2_topk_mfma_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, nq, nx, d, k):
