@@ -216,6 +216,22 @@ def segmented_max(x, coords, n_batch):
     return out
 
 
+def instance_norm(x, seg, weight=None, bias=None, eps=1e-8):
+    """cs_instance_norm: x f32 [n,c] rows grouped by sample, seg int32 [n_batch+1] device row offsets."""
+    x, ld_in = _rows(_dev(x, torch.float32, "input"), "input")
+    seg = _dev(seg, torch.int32, "segment offsets").contiguous()
+    out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    w = _dev(weight, torch.float32, "weight").contiguous().reshape(-1) if weight is not None else None
+    b = _dev(bias, torch.float32, "bias").contiguous().reshape(-1) if bias is not None else None
+    for t, name in ((w, "weight"), (b, "bias")):
+        if t is not None and t.numel() != x.shape[1]:
+            raise ValueError("instance_norm: %s must have %d entries" % (name, x.shape[1]))
+    check(_lib.load().cs_instance_norm(x.shape[0], x.shape[1], ptr(x), ld_in, ptr(seg), seg.numel() - 1,
+                                       ptr(w) if w is not None else None, ptr(b) if b is not None else None,
+                                       float(eps), ptr(out), out.stride(0), stream_ptr()))
+    return out
+
+
 def voxelize(xyz, offsets, voxel_size):
     """cs_voxelize: xyz f32 [n,3] device, offsets host list.  Returns (keep_idx int64 [m],
     grid int32 [m,4], out_offsets list)."""

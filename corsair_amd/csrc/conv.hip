@@ -282,6 +282,85 @@ __global__ void k_segmax_fin(unsigned* buf, int64_t n) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ------------------------------------------------------------------------------------------------
+// Instance normalisation (MinkowskiInstanceNorm of the IN network variants, model/common.py:23-24):
+// per sample and channel  out = (x - mean) / sqrt(var + eps) * weight + bias  with the biased variance.
+// Fixed summation order (the oracle restates it): a sample's rows in chunks of INORM_CHUNK consecutive
+// rows, f64 sequential sum inside a chunk, chunk sums added in chunk order.  mean and var are rounded to
+// f32, 1/sqrt in f64 rounded to f32, the affine part in f32 without contraction.
+// Rows must be grouped by sample (seg[b] .. seg[b+1], the collate order).
+// ------------------------------------------------------------------------------------------------
+constexpr int INORM_CHUNK = 256;
+constexpr int INORM_SLICES = 64;
+
+__device__ __forceinline__ int64_t inorm_slot(const int32_t* seg, int b) { return (int64_t)(seg[b] / INORM_CHUNK) + b; }
+
+// grid (INORM_SLICES, n_batch, channel groups of 256); thread = channel.  PASS 0: sum of x; PASS 1: sum of
+// (x - mean)^2 with the f32 mean of PASS 0.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_inorm_partial(const float* __restrict__ x, int ld, int c,
+                                                       const int32_t* __restrict__ seg,
+                                                       const float* __restrict__ mean,
+                                                       double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const int ch = blockIdx.z * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const int r0 = seg[b], r1 = seg[b + 1];
+  const int chunks = (r1 - r0 + INORM_CHUNK - 1) / INORM_CHUNK;
+  const float m = PASS ? mean[(int64_t)b * c + ch] : 0.f;
+  for (int k = blockIdx.x; k < chunks; k += gridDim.x) {
+    const int a = r0 + k * INORM_CHUNK, e = min(r1, a + INORM_CHUNK);
+    double acc = 0.0;
+    for (int r = a; r < e; ++r) {
+      const float v = x[(int64_t)r * ld + ch];
+      if (PASS) {
+        const float d = v - m;
+        acc += (double)d * (double)d;
+      } else {
+        acc += (double)v;
+      }
+    }
+    partial[(inorm_slot(seg, b) + k) * c + ch] = acc;
+  }
+}
+
+// one thread per (sample, channel): chunk sums in order.  PASS 0 -> mean; PASS 1 -> 1 / sqrt(var + eps)
+template <int PASS>
+__global__ void k_inorm_stat(const double* __restrict__ partial, int c, int n_batch,
+                             const int32_t* __restrict__ seg, float eps, float* __restrict__ stat) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n_batch * c) return;
+  const int b = (int)(t / c), ch = (int)(t - (int64_t)b * c);
+  const int len = seg[b + 1] - seg[b];
+  const int chunks = (len + INORM_CHUNK - 1) / INORM_CHUNK;
+  double acc = 0.0;
+  for (int k = 0; k < chunks; ++k) acc += partial[(inorm_slot(seg, b) + k) * c + ch];
+  if (len == 0) {
+    stat[t] = 0.f;
+    return;
+  }
+  const float v = (float)(acc / (double)len);
+  stat[t] = PASS ? (float)(1.0 / sqrt((double)v + (double)eps)) : v;
+}
+
+__global__ void k_inorm_apply(const float* __restrict__ x, int ld_in, int c, int n_batch,
+                              const int32_t* __restrict__ seg, const float* __restrict__ mean,
+                              const float* __restrict__ inv_std, const float* __restrict__ weight,
+                              const float* __restrict__ bias, float* __restrict__ out, int ld_out) {
+  const int b = blockIdx.y;
+  const int r0 = seg[b], r1 = seg[b + 1];
+  const int64_t total = (int64_t)(r1 - r0) * c;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int r = r0 + (int)(t / c), ch = (int)(t % c);
+    const float d = x[(int64_t)r * ld_in + ch] - mean[(int64_t)b * c + ch];
+    float v = d * inv_std[(int64_t)b * c + ch];
+    if (weight) v = v * weight[ch];
+    if (bias) v = v + bias[ch];
+    out[(int64_t)r * ld_out + ch] = v;
+  }
+}
+
 }  // namespace cs
 
 using namespace cs;
@@ -390,6 +469,32 @@ int cs_segmented_max(int64_t n, int c, const float* d_in, int ld_in, const int32
   hipLaunchKernelGGL(k_segmax_fin, dim3((unsigned)ceil_div(on, 256)), dim3(256), 0, s, obuf, on);
   CS_LAUNCH_CHECK();
   return CS_OK;
+}
+
+int cs_instance_norm(int64_t n, int c, const float* d_in, int ld_in, const int32_t* d_seg, int n_batch,
+                     const float* d_weight, const float* d_bias, float eps, float* d_out, int ld_out,
+                     void* stream) {
+  CS_REQUIRE(d_in && d_out && d_seg && c >= 1 && ld_in >= c && ld_out >= c && n_batch >= 0 && n >= 0 &&
+                 n < (1LL << 31) && eps >= 0.f,
+             CS_ERR_INVALID, "cs_instance_norm: bad argument");
+  if (n == 0 || n_batch == 0) return CS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
+  const int64_t slots = n / INORM_CHUNK + n_batch + 1;
+  PoolBuf<double> partial((size_t)slots * c);
+  PoolBuf<float> mean((size_t)n_batch * c), inv_std((size_t)n_batch * c);
+  CS_REQUIRE(partial.p && mean.p && inv_std.p, CS_ERR_HIP, "cs_instance_norm: scratch allocation failed");
+  const dim3 pg(INORM_SLICES, (unsigned)n_batch, (unsigned)ceil_div(c, 256));
+  const unsigned sg = (unsigned)ceil_div((int64_t)n_batch * c, 256);
+  hipLaunchKernelGGL(k_inorm_partial<0>, pg, dim3(256), 0, s, d_in, ld_in, c, d_seg, (const float*)nullptr,
+                     partial.p);
+  hipLaunchKernelGGL(k_inorm_stat<0>, dim3(sg), dim3(256), 0, s, partial.p, c, n_batch, d_seg, eps, mean.p);
+  hipLaunchKernelGGL(k_inorm_partial<1>, pg, dim3(256), 0, s, d_in, ld_in, c, d_seg, mean.p, partial.p);
+  hipLaunchKernelGGL(k_inorm_stat<1>, dim3(sg), dim3(256), 0, s, partial.p, c, n_batch, d_seg, eps, inv_std.p);
+  hipLaunchKernelGGL(k_inorm_apply, dim3(64, (unsigned)n_batch), dim3(256), 0, s, d_in, ld_in, c, n_batch,
+                     d_seg, mean.p, inv_std.p, d_weight, d_bias, d_out, ld_out);
+  CS_LAUNCH_CHECK();
+  return CS_OK;  // no synchronisation: the scratch returns to this thread's stream-ordered cache
 }
 
 }  // extern "C"

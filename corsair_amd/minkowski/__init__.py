@@ -257,13 +257,21 @@ class MinkowskiBatchNorm(nn.Module):
 
 
 class MinkowskiInstanceNorm(nn.Module):
+    """Per-sample, per-channel normalisation of the rows (the IN variants of the network build their
+    residual blocks with it, model/common.py:23-24, model/resunet.py:311-333).  Parameters `weight` /
+    `bias` of shape [1, C] as in MinkowskiEngine; eps 1e-8 inside the root, biased variance."""
+
     def __init__(self, num_features, dimension=None):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(1, num_features))
         self.bias = nn.Parameter(torch.zeros(1, num_features))
 
     def forward(self, x):
-        raise NotImplementedError("instance-norm ResUNet variants are a later row (SURVEY 8f rank 4)")
+        batch = x.C[:, 0].contiguous()
+        n_batch = int(batch[-1].item()) + 1 if batch.numel() else 0      # rows are grouped by sample
+        seg = torch.searchsorted(batch, torch.arange(n_batch + 1, device=batch.device, dtype=batch.dtype))
+        out = B.instance_norm(x.F, seg.to(torch.int32), self.weight.detach(), self.bias.detach(), 1e-8)
+        return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
 
 
 class MinkowskiReLU(nn.Module):

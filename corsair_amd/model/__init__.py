@@ -2,7 +2,9 @@
 from . import fc, resunet
 
 _MODELS = {c.__name__: c for c in (resunet.ResUNetBN2, resunet.ResUNetBN2B, resunet.ResUNetBN2C,
-                                   resunet.ResUNetBN2D, resunet.ResUNetBN2E)}
+                                   resunet.ResUNetBN2D, resunet.ResUNetBN2E, resunet.ResUNetIN2,
+                                   resunet.ResUNetIN2B, resunet.ResUNetIN2C, resunet.ResUNetIN2D,
+                                   resunet.ResUNetIN2E)}
 _HEADS = {c.__name__: c for c in (fc.conv1_max_embedding, fc.conv1_chamfer)}
 
 

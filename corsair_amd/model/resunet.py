@@ -93,3 +93,29 @@ class ResUNetBN2E(ResUNet2):
     NORM_TYPE = "BN"
     CHANNELS = [None, 128, 128, 128, 256]
     TR_CHANNELS = [None, 64, 128, 128, 128]
+
+
+# instance-norm residual blocks, batch-norm elsewhere (model/resunet.py:311-333 of the reference)
+class ResUNetIN2(ResUNet2):
+    NORM_TYPE = "BN"
+    BLOCK_NORM_TYPE = "IN"
+
+
+class ResUNetIN2B(ResUNetBN2B):
+    NORM_TYPE = "BN"
+    BLOCK_NORM_TYPE = "IN"
+
+
+class ResUNetIN2C(ResUNetBN2C):
+    NORM_TYPE = "BN"
+    BLOCK_NORM_TYPE = "IN"
+
+
+class ResUNetIN2D(ResUNetBN2D):
+    NORM_TYPE = "BN"
+    BLOCK_NORM_TYPE = "IN"
+
+
+class ResUNetIN2E(ResUNetBN2E):
+    NORM_TYPE = "BN"
+    BLOCK_NORM_TYPE = "IN"

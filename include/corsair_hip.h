@@ -122,6 +122,17 @@ int cs_row_l2_normalize(int64_t n, int c, const float* d_in, int ld_in, float ep
 int cs_segmented_max(int64_t n, int c, const float* d_in, int ld_in, const int32_t* d_batch,
                      int batch_ld, int n_batch, float* d_out, void* stream);
 
+/* Instance normalisation over the rows of every sample (ME.MinkowskiInstanceNorm, used by the IN
+ * variants of the network through model/common.py:23-24; MinkowskiEngine semantics: biased variance,
+ * eps 1e-8 added to the variance, affine weight / bias [c]):
+ *   out[r, ch] = (in[r, ch] - mean[b, ch]) / sqrt(var[b, ch] + eps) * weight[ch] + bias[ch].
+ * d_seg: int32 [n_batch + 1] DEVICE row offsets of the samples (rows grouped by sample, ascending);
+ * d_weight / d_bias may be NULL.  Summation order is fixed (see conv.hip) so that the CPU oracle
+ * reproduces the result bit for bit.  Returns without waiting for the stream. */
+int cs_instance_norm(int64_t n, int c, const float* d_in, int ld_in, const int32_t* d_seg, int n_batch,
+                     const float* d_weight, const float* d_bias, float eps, float* d_out, int ld_out,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Voxel quantisation.  Replaces ME.utils.sparse_quantize(floor(xyz/voxel), return_index=True,
  * return_maps_only=True) (utils/Info/CADLib.py:106-121, datasets/CategoryDataset.py:179-197):

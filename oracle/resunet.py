@@ -1,4 +1,5 @@
-"""CPU restatement of the sparse ResUNetBN2C forward + global embedding head.
+"""CPU restatement of the sparse ResUNetBN2C forward (and of the instance-norm block variants,
+model/resunet.py:311-333, chosen by the state dict) + global embedding head.
 TEST INFRASTRUCTURE ONLY.
 
 Follows the graph of the reference's model code, read as text:
@@ -56,7 +57,27 @@ def build_maps(coords):
     return {"c1": c1, "c2": c2, "c4": c4, "c8": c8}, km
 
 
-def _block(w, prefix, x, nbr):
+def _seg_of(coords):
+    """Row offsets of the samples of a coordinate map (rows grouped by batch index)."""
+    b = np.asarray(coords)[:, 0]
+    n_batch = int(b[-1]) + 1 if len(b) else 0
+    return np.searchsorted(b, np.arange(n_batch + 1))
+
+
+def _block_in(w, prefix, x, nbr, seg):
+    """BasicBlockIN (model/residual_block.py:60-73 with NORM_TYPE "IN"): conv, instance norm, ReLU, conv,
+    instance norm, + input, ReLU -- op by op, as the MinkowskiEngine modules run it."""
+    y = native.conv_fwd(nbr, x, w[prefix + ".conv1.kernel"], None, None, None, False)
+    y = sparse.instance_norm(y, seg, w[prefix + ".norm1.weight"], w[prefix + ".norm1.bias"])
+    y = np.maximum(y, np.float32(0))
+    y = native.conv_fwd(nbr, y, w[prefix + ".conv2.kernel"], None, None, None, False)
+    y = sparse.instance_norm(y, seg, w[prefix + ".norm2.weight"], w[prefix + ".norm2.bias"])
+    return np.maximum((y + np.asarray(x, np.float32)).astype(np.float32), np.float32(0))
+
+
+def _block(w, prefix, x, nbr, seg=None):
+    if prefix + ".norm1.weight" in w:       # instance-norm block (the IN network variants)
+        return _block_in(w, prefix, x, nbr, seg)
     s1, b1 = fold_bn(w, prefix + ".norm1")
     s2, b2 = fold_bn(w, prefix + ".norm2")
     y = native.conv_fwd(nbr, x, w[prefix + ".conv1.kernel"], s1, b1, None, True)
@@ -72,17 +93,18 @@ def resunet_forward(w, coords, feats, normalize_feature=True):
         s, b = fold_bn(w, norm)
         return native.conv_fwd(nbr, x, w[name + ".kernel"], s, b, None, False)
 
-    out_s1 = _block(w, "block1", conv_bn("conv1", "norm1", x, km["s1"]), km["s1"])
-    out_s2 = _block(w, "block2", conv_bn("conv2", "norm2", out_s1, km["s1_s2"]), km["s2"])
-    out_s4 = _block(w, "block3", conv_bn("conv3", "norm3", out_s2, km["s2_s4"]), km["s4"])
-    out_s8 = _block(w, "block4", conv_bn("conv4", "norm4", out_s4, km["s4_s8"]), km["s8"])
+    g1, g2, g4, g8 = (_seg_of(maps[k]) for k in ("c1", "c2", "c4", "c8"))
+    out_s1 = _block(w, "block1", conv_bn("conv1", "norm1", x, km["s1"]), km["s1"], g1)
+    out_s2 = _block(w, "block2", conv_bn("conv2", "norm2", out_s1, km["s1_s2"]), km["s2"], g2)
+    out_s4 = _block(w, "block3", conv_bn("conv3", "norm3", out_s2, km["s2_s4"]), km["s4"], g4)
+    out_s8 = _block(w, "block4", conv_bn("conv4", "norm4", out_s4, km["s4_s8"]), km["s8"], g8)
     feat = out_s8  # block output is already >= 0, MEF.relu at resunet.py:227 is idempotent
 
-    out = _block(w, "block4_tr", conv_bn("conv4_tr", "norm4_tr", out_s8, km["s8_s4_T"]), km["s4"])
+    out = _block(w, "block4_tr", conv_bn("conv4_tr", "norm4_tr", out_s8, km["s8_s4_T"]), km["s4"], g4)
     out = np.concatenate([out, out_s4], 1)
-    out = _block(w, "block3_tr", conv_bn("conv3_tr", "norm3_tr", out, km["s4_s2_T"]), km["s2"])
+    out = _block(w, "block3_tr", conv_bn("conv3_tr", "norm3_tr", out, km["s4_s2_T"]), km["s2"], g2)
     out = np.concatenate([out, out_s2], 1)
-    out = _block(w, "block2_tr", conv_bn("conv2_tr", "norm2_tr", out, km["s2_s1_T"]), km["s1"])
+    out = _block(w, "block2_tr", conv_bn("conv2_tr", "norm2_tr", out, km["s2_s1_T"]), km["s1"], g1)
     out = np.concatenate([out, out_s1], 1)
     out = native.conv_fwd(None, out, w["conv1_tr.kernel"], None, None, None, True)
     out = native.conv_fwd(None, out, w["final.kernel"], None,

@@ -131,6 +131,46 @@ def kernel_map_triples(nbr):
     return kk.astype(np.int32), nbr[oo, kk].astype(np.int32), oo.astype(np.int32)
 
 
+INORM_CHUNK = 256
+
+
+def instance_norm(feats, seg, weight=None, bias=None, eps=1e-8):
+    """ME.MinkowskiInstanceNorm over the rows of every sample (model/common.py:23-24; IN network variants):
+    (x - mean) / sqrt(var + eps) * weight + bias, biased variance, eps 1e-8 inside the root
+    [ME-knowledge, unpinned].  seg: row offsets of the samples.  Arithmetic as the library defines it: f64
+    sums over chunks of 256 consecutive rows of a sample (sequential inside a chunk, chunk sums added in
+    order), mean / var rounded to f32, 1/sqrt in f64 rounded to f32, affine part in f32."""
+    x = np.asarray(feats, dtype=np.float32)
+    out = np.empty_like(x)
+    f32 = np.float32
+
+    def chunked_sum(v):                      # v f64 [rows, c]: sequential over rows inside 256-row chunks
+        tot = np.zeros(v.shape[1], np.float64)
+        for a in range(0, len(v), INORM_CHUNK):
+            acc = np.zeros(v.shape[1], np.float64)
+            for row in v[a:a + INORM_CHUNK]:
+                acc = acc + row
+            tot = tot + acc
+        return tot
+
+    for b in range(len(seg) - 1):
+        r0, r1 = int(seg[b]), int(seg[b + 1])
+        if r1 == r0:
+            continue
+        xs = x[r0:r1]
+        mean = (chunked_sum(xs.astype(np.float64)) / float(r1 - r0)).astype(f32)
+        d = (xs - mean[None, :]).astype(f32)
+        var = (chunked_sum(d.astype(np.float64) * d.astype(np.float64)) / float(r1 - r0)).astype(f32)
+        inv = (1.0 / np.sqrt(var.astype(np.float64) + np.float64(f32(eps)))).astype(f32)
+        v = (d * inv[None, :]).astype(f32)
+        if weight is not None:
+            v = (v * np.asarray(weight, f32).reshape(1, -1)).astype(f32)
+        if bias is not None:
+            v = (v + np.asarray(bias, f32).reshape(1, -1)).astype(f32)
+        out[r0:r1] = v
+    return out
+
+
 def segmented_max(feats, batch_index, n_batch):
     """Per-sample column-wise max (model/fc.py:23-29,124-125)."""
     feats = np.asarray(feats, dtype=np.float32)

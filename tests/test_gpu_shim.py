@@ -59,6 +59,52 @@ def test_model_code_on_shim_matches_engine_and_oracle(gpu, oracle_native):
     assert set(head.state_dict().keys()) == set(emb.keys())
 
 
+@pytest.mark.parametrize("c,ld_pad", [(32, 0), (300, 4), (1, 0)])
+def test_instance_norm_bit_exact(gpu, c, ld_pad):
+    """cs_instance_norm against the oracle: ragged samples around the 256-row chunk size, an empty sample,
+    more than 256 channels, a strided input view."""
+    from corsair_amd import backend as B
+    from oracle import sparse
+
+    rng = np.random.default_rng(c)
+    seg = [0, 255, 511, 511, 1024, 1025, 1900]
+    full = (rng.normal(size=(seg[-1], c + ld_pad)) * 3 + 1).astype(np.float32)
+    x = torch.from_numpy(full).to(gpu)[:, :c]                       # ld = c + ld_pad
+    w = rng.normal(size=(1, c)).astype(np.float32)
+    b = rng.normal(size=(1, c)).astype(np.float32)
+    seg_t = torch.tensor(seg, dtype=torch.int32, device=gpu)
+    got = B.instance_norm(x, seg_t, torch.from_numpy(w).to(gpu), torch.from_numpy(b).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, sparse.instance_norm(full[:, :c], seg, w, b))
+    got = B.instance_norm(x, seg_t).cpu().numpy()
+    assert np.array_equal(got, sparse.instance_norm(full[:, :c], seg))
+
+
+def test_instance_norm_network_variant_matches_oracle(gpu, oracle_native):
+    """ResUNetIN2C (instance-norm residual blocks, model/resunet.py:323-325) built from the ME-compatible
+    modules == the oracle's op-by-op restatement, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "shim"))
+    import MinkowskiEngine as ME  # noqa: the shim package
+
+    from corsair_amd.model import load_model
+    from oracle import resunet as oref
+
+    coords, feats, _, _ = make_batch([11, 12, 13], n_points=3000)
+    torch.manual_seed(5)
+    model = load_model("ResUNetIN2C")(1, 16, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=3, D=3)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ".norm" in name and name.startswith("block"):        # affine part of the instance norms
+                p.copy_(torch.randn_like(p) * 0.3 + (1.0 if name.endswith("weight") else 0.0))
+    model = model.to(gpu).eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    assert "block1.norm1.weight" in sd and "block1.norm1.bn.weight" not in sd and "norm1.bn.weight" in sd
+    with torch.no_grad():
+        out, feat = model(ME.SparseTensor(torch.from_numpy(feats).to(gpu), torch.from_numpy(coords).to(gpu)))
+    want_out, want_feat, _ = oref.resunet_forward(sd, coords, feats)
+    assert np.array_equal(feat.F.cpu().numpy(), want_feat)
+    assert np.array_equal(out.F.cpu().numpy(), want_out)
+
+
 def test_shim_sparse_tensor_semantics(gpu):
     sys.path.insert(0, os.path.join(ROOT, "shim"))
     import MinkowskiEngine as ME

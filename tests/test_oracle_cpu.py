@@ -369,3 +369,47 @@ def test_sym_pose_host_logic_part_configs():
     assert R.draw_anchors(50, 100, 0) is None
     a = R.draw_anchors(500, 100, 3)
     assert len(np.unique(a)) == 100 and np.array_equal(a, R.draw_anchors(500, 100, 3))
+
+
+def test_instance_norm_oracle_matches_plain_definition():
+    """oracle.sparse.instance_norm (chunked f64 sums, f32 roundings) against the textbook formula in f64."""
+    from oracle import sparse
+
+    rng = np.random.default_rng(3)
+    seg = [0, 700, 700, 1213, 1214]                 # ragged, one empty sample, one single-row sample
+    x = (rng.normal(size=(seg[-1], 24)) * rng.uniform(0.1, 5, 24) + rng.normal(size=24)).astype(np.float32)
+    w = rng.normal(size=(1, 24)).astype(np.float32)
+    b = rng.normal(size=(1, 24)).astype(np.float32)
+    got = sparse.instance_norm(x, seg, w, b)
+    for i in range(len(seg) - 1):
+        xs = x[seg[i]:seg[i + 1]].astype(np.float64)
+        if len(xs) == 0:
+            continue
+        want = (xs - xs.mean(0)) / np.sqrt(xs.var(0) + 1e-8) * w.astype(np.float64) + b.astype(np.float64)
+        assert np.allclose(got[seg[i]:seg[i + 1]], want, rtol=2e-5, atol=2e-5)
+    # no affine part
+    assert np.allclose(sparse.instance_norm(x, seg)[:700].mean(0), 0, atol=1e-5)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """utils/ckpts.py:21-63 format: save_checkpoint -> load_checkpoint / load_state_dicts."""
+    import torch
+
+    from corsair_amd.utils import ckpts
+
+    model, head = torch.nn.Linear(3, 2), torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(list(model.parameters()) + list(head.parameters()), lr=0.1)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.9)
+    ckpts.save_checkpoint(model, head, opt, sched, 7, str(tmp_path / "out"), "ckpt.pth")
+    path = str(tmp_path / "out" / "ckpt.pth")
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"state_dict", "embedding_state_dict", "optimizer", "scheduler", "epoch"}
+    m2, h2 = torch.nn.Linear(3, 2), torch.nn.Linear(2, 2)
+    o2 = torch.optim.SGD(list(m2.parameters()) + list(h2.parameters()), lr=0.5)
+    s2 = torch.optim.lr_scheduler.ExponentialLR(o2, 0.9)
+    _, _, _, epoch = ckpts.load_checkpoint(m2, h2, o2, s2, path)
+    assert epoch == 7 and torch.equal(m2.weight, model.weight) and torch.equal(h2.bias, head.bias)
+    sd, esd = ckpts.load_state_dicts(path)
+    assert set(sd) == {"weight", "bias"} and esd is not None
+    ckpts.save_checkpoint(model, None, opt, sched, 8, str(tmp_path / "out"), "net_only.pth")
+    assert "embedding_state_dict" not in torch.load(str(tmp_path / "out" / "net_only.pth"), weights_only=False)
