@@ -1166,6 +1166,221 @@ __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same shortlist on the f16 matrix cores (d = 64 / 128 / 256, k <= 10): 16x the f64 matrix rate.
+// s~ = |x|^2 - 2 q.x with x = x_hi + x_lo and v = -2 q = v_hi + v_lo split into f16 (the lo * lo
+// products are dropped): 3 v_mfma_f32_32x32x16_f16 per 16 features of a 32 x 32 (catalog x query) tile,
+// accumulator preloaded with |x|^2.  Queries live in registers (32 per wave, 8 waves per workgroup:
+// 256 queries reuse every staged catalog row), the catalog streams through LDS as a padded f16 image
+// (row = [hi(16) | lo(16)] per 16 features + 16 B: odd 16-B slot pitch, conflict-free ds_read_b128),
+// 64 rows per stage, copied by LDS-DMA one stage ahead.  A lane keeps the TKF_KK best rows of its half
+// of the tile rows.  Exactness: the shortlist is re-scored with the canonical f64 chain (k_topk_rescore)
+// and VERIFIED -- every row outside the shortlist has s~ >= tau (the smallest of the lanes' TKF_KK-th
+// values), hence exact s >= tau - eps with eps = (3 d + 4) 2^-22 (|q|^2 + max |x|^2) bounding the f16
+// pipeline error (split residuals 3 * 2^-21 |q||x|, 3 d + 1 f32 accumulations of partial sums
+// <= |x|^2 + 2 |q||x|); queries whose exact k-th value is not below that go through the f64 path.
+// ------------------------------------------------------------------------------------------
+constexpr int TKF_ROWS = 64;   // catalog rows per LDS stage (2 MFMA row tiles)
+constexpr int TKF_QT = 256;    // queries per workgroup (8 waves x 32)
+constexpr int TKF_KK = 12;     // shortlist per lane (two lanes per query and catalog split)
+
+// f16 image of n rows (+ zero rows up to n_pad): per 16 features [hi(16) | lo(16)] of scale * X
+__global__ void k_tkf_pack(const float* __restrict__ X, int64_t n, int64_t n_pad, int d, float scale,
+                           _Float16* __restrict__ img, int pitch_h) {
+  const int dch = d / 16;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n_pad * dch) return;
+  const int64_t row = t / dch;
+  const int c = (int)(t - row * dch);
+  union {
+    _Float16 h[32];
+    uint4 v[4];
+  } u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double v = row < n ? (double)scale * (double)X[row * d + c * 16 + j] : 0.0;
+    const _Float16 hi = (_Float16)v;
+    u.h[j] = hi;
+    u.h[16 + j] = (_Float16)(v - (double)hi);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(img + row * pitch_h + c * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dst[j] = u.v[j];
+  if (c == 0 && pitch_h > dch * 32) {  // the 16-B pad of a catalog row (never read by the MFMA fragments; keep it defined)
+    uint4* pad = reinterpret_cast<uint4*>(img + row * pitch_h + dch * 32);
+    *pad = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+__global__ void k_max_bits(const double* __restrict__ v, int64_t n, unsigned* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  float m = i < n ? __double2float_ru(v[i]) : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));  // non-negative floats order like uints
+}
+
+// grid: x = query tile (TKF_QT), y = catalog split; 512 threads; dynamic LDS: 2 stages + 2 x TKF_ROWS floats.
+// cand_i: [nq][nsplit * 2][TKF_KK], tau: [nq][nsplit * 2]
+template <int DCH>
+__global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ qimg, int64_t nq,
+                                                  const _Float16* __restrict__ ximg, int64_t nx,
+                                                  const double* __restrict__ xn, int nsplit,
+                                                  int* __restrict__ cand_i, float* __restrict__ tau) {
+  constexpr int PITCH_B = DCH * 64 + 16;              // bytes per image row
+  constexpr int STAGE_BYTES = TKF_ROWS * PITCH_B;     // whole KiB for DCH = 4, 8, 16
+  constexpr int STAGE_KIB = STAGE_BYTES / 1024;
+  static_assert(STAGE_BYTES % 1024 == 0, "a stage must be whole 1-KiB LDS-DMA instructions");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  float* tn_s = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES);  // [2][TKF_ROWS]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int col = lane & 31;
+  const int64_t my_q = (int64_t)blockIdx.x * TKF_QT + wave * 32 + col;
+  const int64_t per = ((nx + nsplit - 1) / nsplit + TKF_ROWS - 1) / TKF_ROWS * TKF_ROWS;
+  const int64_t xb = (int64_t)blockIdx.y * per;
+  const int64_t xe = min(nx, xb + per);
+  // B operands of the wave's 32 queries: lane supplies k = 8 half .. +8 of every 16-feature chunk
+  f16x8 qh[DCH], ql[DCH];
+  {
+    const _Float16* qrow = qimg + (my_q < nq ? my_q : 0) * (int64_t)(DCH * 32) + 8 * half;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      qh[c] = *reinterpret_cast<const f16x8*>(qrow + c * 32);
+      ql[c] = *reinterpret_cast<const f16x8*>(qrow + c * 32 + 16);
+    }
+  }
+  float bd[TKF_KK];
+  int bi[TKF_KK];
+#pragma unroll
+  for (int j = 0; j < TKF_KK; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+  const char* gimg = reinterpret_cast<const char*>(ximg) + lane * 16;
+  auto issue_stage = [&](int b, int64_t base) {
+    const char* gp = gimg + base * PITCH_B;
+#pragma unroll
+    for (int i = 0; i < (STAGE_KIB + 7) / 8; ++i) {
+      const int piece = wave + 8 * i;  // wave-uniform
+      if (piece < STAGE_KIB)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024),
+                                         (__attribute__((address_space(3))) void*)(lds + b * STAGE_BYTES + piece * 1024),
+                                         16, 0, 0);
+    }
+    if (tid < TKF_ROWS) tn_s[b * TKF_ROWS + tid] = base + tid < xe ? (float)xn[base + tid] : INFINITY;
+  };
+  if (xb < xe) issue_stage(0, xb);
+  int buf = 0;
+  for (int64_t base = xb; base < xe; base += TKF_ROWS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (base + TKF_ROWS < xe) issue_stage(buf ^ 1, base + TKF_ROWS);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // accumulator input: |x|^2 of the 16 rows this lane owns: (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 v = *reinterpret_cast<const float4*>(&tn_s[buf * TKF_ROWS + t * 32 + 8 * q4 + 4 * half]);
+        acc[t][4 * q4 + 0] = v.x; acc[t][4 * q4 + 1] = v.y; acc[t][4 * q4 + 2] = v.z; acc[t][4 * q4 + 3] = v.w;
+      }
+    }
+    const char* st = lds + buf * STAGE_BYTES + col * PITCH_B + half * 16;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64 + 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[t][r];
+        if (v < bd[TKF_KK - 1]) {
+          float cd = v;
+          int ci = (int)(base + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+          bool carry = false;
+#pragma unroll
+          for (int s2 = 0; s2 < TKF_KK; ++s2) {
+            if (carry || cd < bd[s2]) {
+              carry = true;
+              const float td = bd[s2];
+              const int ti = bi[s2];
+              bd[s2] = cd;
+              bi[s2] = ci;
+              cd = td;
+              ci = ti;
+            }
+          }
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  if (my_q < nq) {
+    const int64_t slot = my_q * (nsplit * 2) + blockIdx.y * 2 + half;
+#pragma unroll
+    for (int j = 0; j < TKF_KK; ++j) cand_i[slot * TKF_KK + j] = bi[j];
+    tau[slot] = bd[TKF_KK - 1];
+  }
+}
+
+template <int DCH>
+static int launch_topk_f16(dim3 grid, hipStream_t s, const _Float16* qimg, int64_t nq, const _Float16* ximg,
+                           int64_t nx, const double* xn, int nsplit, int* cand_i, float* tau) {
+  constexpr int LDS_BYTES = 2 * TKF_ROWS * (DCH * 64 + 16) + 2 * TKF_ROWS * (int)sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_f16<DCH>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  CS_REQUIRE(attr == hipSuccess, CS_ERR_HIP, "cs_l2_topk: cannot reserve %d bytes of LDS", LDS_BYTES);
+  hipLaunchKernelGGL(k_topk_f16<DCH>, grid, dim3(512), LDS_BYTES, s, qimg, nq, ximg, nx, xn, nsplit, cand_i, tau);
+  return CS_OK;
+}
+
+// One thread per query: is the re-scored k-th value provably below everything outside the shortlist?
+// flagged queries (compact list + count) go through the f64 path.
+__global__ void k_tkf_verify(const unsigned long long* __restrict__ carry_d, int k, int64_t nq,
+                             const float* __restrict__ tau, int nlane, const double* __restrict__ qn,
+                             const unsigned* __restrict__ xmax_bits, int d, int* __restrict__ flagged,
+                             int* __restrict__ n_flagged) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  float t = INFINITY;
+  for (int j = 0; j < nlane; ++j) t = fminf(t, tau[q * nlane + j]);
+  const double dk = __longlong_as_double((long long)carry_d[q * k + k - 1]);   // exact k-th squared distance
+  const double eps = (double)(3 * d + 4) * 2.384185791015625e-07 * (qn[q] + (double)__uint_as_float(*xmax_bits));
+  const bool ok = dk - qn[q] < (double)t - eps;   // false for NaN / missing candidates
+  if (!ok) flagged[atomicAdd(n_flagged, 1)] = (int)q;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ X, int d, const int* __restrict__ rows, int64_t n,
+                              float* __restrict__ out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * d) return;
+  const int64_t r = t / d;
+  out[t] = X[(int64_t)rows[r] * d + (t - r * d)];
+}
+
+__global__ void k_scatter_topk(const int64_t* __restrict__ idx, const double* __restrict__ dist, int k,
+                               const int* __restrict__ rows, int64_t n, int64_t* __restrict__ out_idx,
+                               double* __restrict__ out_dist) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * k) return;
+  const int64_t r = t / k;
+  const int64_t o = (int64_t)rows[r] * k + (t - r * k);
+  out_idx[o] = idx[t];
+  if (out_dist) out_dist[o] = dist[t];
+}
+
 // ------------------------------------------------------------------------------------------
 // one-directional Chamfer
 // ------------------------------------------------------------------------------------------
@@ -1573,6 +1788,108 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
 
+// f64 matrix-pipe shortlist + canonical re-score (k <= TKM_KK - 2)
+static int topk_f64_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
+                              int64_t* d_idx, double* d_dist, hipStream_t s) {
+  int nsplit = (int)(2048 / ceil_div(nq, TKM_QT));
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 64) nsplit = 64;
+  while (nsplit > 1 && (nx / nsplit < 4 * TKM_XT || nsplit * 4 * TKM_KK > TKM_MERGE_CAP)) --nsplit;
+  const int ncand = nsplit * 4 * TKM_KK;
+  PoolBuf<double> qn(nq), xn(nx), cand_d((size_t)nq * ncand);
+  PoolBuf<int> cand_i((size_t)nq * ncand);
+  PoolBuf<unsigned long long> cd((size_t)nq * k);
+  PoolBuf<int> ci((size_t)nq * k);
+  CS_REQUIRE(qn.p && xn.p && cand_d.p && cand_i.p && cd.p && ci.p, CS_ERR_HIP,
+             "cs_l2_topk: scratch allocation failed");
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn.p);
+  hipLaunchKernelGGL(k_topk_mfma, dim3((unsigned)ceil_div(nq, TKM_QT), (unsigned)nsplit), dim3(256), 0,
+                     s, d_q, nq, d_x, nx, d, qn.p, xn.p, nsplit, cand_d.p, cand_i.p);
+  hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand,
+                     k, cd.p, ci.p);
+  hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
+                     ci.p, nq * k, d_idx, d_dist);
+  CS_LAUNCH_CHECK();
+  return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
+}
+
+// {queries through the f16 shortlist, of those recomputed by the f64 path}
+static std::atomic<unsigned long long> g_topk_stats[2];
+
+// f16 matrix-core shortlist (d = 64 / 128 / 256, k <= 10), canonical re-score, verification, f64 path for
+// the queries that fail it.  Waits for the stream once (the number of such queries).
+static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
+                              int64_t* d_idx, double* d_dist, hipStream_t s) {
+  const int dch = d / 16;
+  const int pitch_h = dch * 32 + 8;  // halfs per catalog image row (16 B of padding)
+  const int64_t qtiles = ceil_div(nq, TKF_QT);
+  int nsplit = (int)ceil_div(512, qtiles);
+  if (nsplit > 32) nsplit = 32;
+  while (nsplit > 1 && nx / nsplit < 8 * TKF_ROWS) --nsplit;
+  if (nsplit < 1) nsplit = 1;
+  const int nlane = nsplit * 2;
+  const int ncand = nlane * TKF_KK;  // <= 768 <= TKM_MERGE_CAP
+  const int64_t n_pad = ceil_div(nx, TKF_ROWS) * TKF_ROWS;
+  PoolBuf<_Float16> qimg((size_t)nq * dch * 32), ximg((size_t)n_pad * pitch_h);
+  PoolBuf<double> qn(nq), xn(nx);
+  PoolBuf<unsigned> xmax(1);
+  PoolBuf<int> cand_i((size_t)nq * ncand), ci((size_t)nq * k), flagged((size_t)nq + 1);
+  PoolBuf<float> tau((size_t)nq * nlane);
+  PoolBuf<unsigned long long> cd((size_t)nq * k);
+  CS_REQUIRE(qimg.p && ximg.p && qn.p && xn.p && xmax.p && cand_i.p && ci.p && flagged.p && tau.p && cd.p,
+             CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
+  int* const n_flagged = flagged.p + nq;
+  CS_HIP_CHECK(hipMemsetAsync(xmax.p, 0, sizeof(unsigned), s));
+  CS_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn.p);
+  hipLaunchKernelGGL(k_max_bits, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, xn.p, nx, xmax.p);
+  hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(nq * dch, 256)), dim3(256), 0, s, d_q, nq, nq, d,
+                     -2.0f, qimg.p, dch * 32);
+  hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(n_pad * dch, 256)), dim3(256), 0, s, d_x, nx, n_pad,
+                     d, 1.0f, ximg.p, pitch_h);
+  const dim3 grid((unsigned)qtiles, (unsigned)nsplit);
+  int rc = dch == 16  ? launch_topk_f16<16>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
+           : dch == 8 ? launch_topk_f16<8>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
+                      : launch_topk_f16<4>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand, k,
+                     cd.p, ci.p);
+  hipLaunchKernelGGL(k_tkf_verify, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, cd.p, k, nq, tau.p,
+                     nlane, qn.p, xmax.p, d, flagged.p, n_flagged);
+  hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p, ci.p,
+                     nq * k, d_idx, d_dist);
+  CS_LAUNCH_CHECK();
+  int h_flagged = 0;
+  CS_HIP_CHECK(download_async(&h_flagged, n_flagged, sizeof(int), s));
+  CS_HIP_CHECK(download_sync(s));
+  g_topk_stats[0] += (unsigned long long)nq;
+  g_topk_stats[1] += (unsigned long long)h_flagged;
+  if (h_flagged > 0) {
+    const int64_t nf = h_flagged;
+    PoolBuf<float> qf((size_t)nf * d);
+    PoolBuf<int64_t> fi((size_t)nf * k);
+    PoolBuf<double> fd((size_t)nf * k);
+    CS_REQUIRE(qf.p && fi.p && fd.p, CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div(nf * d, 256)), dim3(256), 0, s, d_q, d, flagged.p,
+                       nf, qf.p);
+    rc = topk_f64_shortlist(qf.p, nf, d_x, nx, d, k, fi.p, fd.p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_topk, dim3((unsigned)ceil_div(nf * k, 256)), dim3(256), 0, s, fi.p, fd.p, k,
+                       flagged.p, nf, d_idx, d_dist);
+    CS_LAUNCH_CHECK();
+  }
+  return CS_OK;
+}
+
+void cs_l2_topk_stats(uint64_t out[2], int reset) {
+  for (int i = 0; i < 2; ++i) {
+    if (out) out[i] = g_topk_stats[i].load();
+    if (reset) g_topk_stats[i].store(0);
+  }
+}
+
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
                int64_t* d_idx, double* d_dist, void* stream) {
   CS_REQUIRE(d_q && d_x && d_idx, CS_ERR_INVALID, "cs_l2_topk: NULL argument");
@@ -1583,32 +1900,16 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
   ProfScope prof("topk", s, 2.0 * (double)nq * (double)nx * (double)d);
-  // large problems with a short list: shortlist on the f64 matrix pipe, exact re-score
+  // Large problems with a short list: shortlist on the matrix cores, exact re-score.  CS_TOPK_MFMA: "0"
+  // exact slab path, "1" / "64" f64 matrix pipe, "16" f16 matrix cores (where the shape allows), unset:
+  // f16 where the shape allows, else f64, for nq * nx >= 2^24.
   const char* force = getenv("CS_TOPK_MFMA");
   const bool big = (double)nq * (double)nx >= 16777216.0;
-  if (k <= TKM_KK - 2 && ((force && force[0] == '1') || (!force && big))) {
-    int nsplit = (int)(2048 / ceil_div(nq, TKM_QT));
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 64) nsplit = 64;
-    while (nsplit > 1 && (nx / nsplit < 4 * TKM_XT || nsplit * 4 * TKM_KK > TKM_MERGE_CAP)) --nsplit;
-    const int ncand = nsplit * 4 * TKM_KK;
-    PoolBuf<double> qn(nq), xn(nx), cand_d((size_t)nq * ncand);
-    PoolBuf<int> cand_i((size_t)nq * ncand);
-    PoolBuf<unsigned long long> cd((size_t)nq * k);
-    PoolBuf<int> ci((size_t)nq * k);
-    CS_REQUIRE(qn.p && xn.p && cand_d.p && cand_i.p && cd.p && ci.p, CS_ERR_HIP,
-               "cs_l2_topk: scratch allocation failed");
-    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
-    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn.p);
-    hipLaunchKernelGGL(k_topk_mfma, dim3((unsigned)ceil_div(nq, TKM_QT), (unsigned)nsplit), dim3(256), 0,
-                       s, d_q, nq, d_x, nx, d, qn.p, xn.p, nsplit, cand_d.p, cand_i.p);
-    hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand,
-                       k, cd.p, ci.p);
-    hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
-                       ci.p, nq * k, d_idx, d_dist);
-    CS_LAUNCH_CHECK();
-    return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
-  }
+  const bool f16_shape = (d == 64 || d == 128 || d == 256) && k <= TKF_KK - 2 && nx >= TKF_ROWS;
+  const bool want16 = force ? (force[0] == '1' && force[1] == '6') : big;
+  const bool want64 = force ? (force[0] == '1' || force[0] == '6') : big;
+  if (want16 && f16_shape) return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);
+  if (want64 && k <= TKM_KK - 2) return topk_f64_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);
   // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
   int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);
   if (slab < DM_CT) slab = DM_CT;

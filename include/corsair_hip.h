@@ -153,6 +153,10 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
  * ---------------------------------------------------------------------------------------- */
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
                int64_t* d_idx, double* d_dist, void* stream);
+/* Diagnostics of the large-size path (nq * nx >= 2^24, d = 64 / 128 / 256, k <= 10: shortlist on the
+ * f16 matrix cores, exact re-score, verification): {queries that took it, queries recomputed by the
+ * f64 path because the verification failed (ties at the k-th neighbour)}. */
+void cs_l2_topk_stats(uint64_t out[2], int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Batched feature k-NN.  Replaces find_knn_cpu / KDTree(feat1).query(feat0, k)

@@ -351,6 +351,69 @@ def test_l2_topk_mfma_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, 
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
 
 
+def _topk_stats(reset=False):
+    import ctypes
+
+    from corsair_amd import _lib
+
+    out = (ctypes.c_uint64 * 2)()
+    _lib.load().cs_l2_topk_stats(out, int(reset))
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("nq,nx,d,k", [(37, 5000, 256, 10), (300, 9000, 128, 1), (130, 20000, 64, 10),
+                                       (5, 64, 256, 3), (700, 777, 256, 10)])
+def test_l2_topk_f16_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, nq, nx, d, k):
+    """The f16 matrix-core shortlist + exact re-score + verification path returns exactly the ids and
+    distances of the canonical chain; exact ties at the k-th neighbour (duplicated catalog rows) make the
+    verification fail and those queries are recomputed by the f64 path."""
+    from corsair_amd import backend as B, synth
+
+    monkeypatch.setenv("CS_TOPK_MFMA", "16")
+    q = synth.make_descriptors(nq, d, seed=21)
+    x = synth.make_descriptors(nx, d, seed=22)
+    x[7] = x[3]
+    x[nx - 1] = x[3]
+    q[0] = x[3]                                   # query 0: three catalog rows at distance 0
+    _topk_stats(reset=True)
+    idx, dist = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(x).to(gpu), k, True)
+    took, fell_back = _topk_stats()
+    assert took == nq and fell_back <= max(2, nq // 20)
+    d2 = oracle_native.dist2_matrix(q, x)
+    want = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
+
+
+def test_l2_topk_f16_falls_back_on_ties_and_scales(gpu, oracle_native, monkeypatch):
+    """600 copies of one catalog row: for the query next to it more rows tie at the k-th neighbour than
+    the shortlist holds, the verification cannot succeed and the query is recomputed by the f64 path --
+    same ids (smallest indices first) as the canonical chain.  Un-normalised descriptors (norms 0.1 .. 40)
+    keep the bound valid for everybody else."""
+    from corsair_amd import backend as B, synth
+
+    monkeypatch.setenv("CS_TOPK_MFMA", "16")
+    q = (synth.make_descriptors(50, 128, seed=31) * np.linspace(0.1, 40, 50)[:, None]).astype(np.float32)
+    base = (synth.make_descriptors(1500, 128, seed=32) * np.linspace(0.5, 30, 1500)[:, None]).astype(np.float32)
+    x = np.concatenate([base, np.repeat(base[17:18], 600, axis=0)])
+    q[0] = base[17] * np.float32(1.001)
+    _topk_stats(reset=True)
+    idx, dist = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(x).to(gpu), 5, True)
+    took, fell_back = _topk_stats()
+    assert took == 50 and 1 <= fell_back <= 5
+    d2 = oracle_native.dist2_matrix(q, x)
+    want = np.argsort(d2, axis=1, kind="stable")[:, :5]
+    assert want[0].tolist() == [17, 1500, 1501, 1502, 1503]
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
+    # without the copies everything verifies
+    _topk_stats(reset=True)
+    idx, _ = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(base).to(gpu), 5, True)
+    took, fell_back = _topk_stats()
+    assert took == 50 and fell_back == 0
+    assert np.array_equal(idx.cpu().numpy(), np.argsort(oracle_native.dist2_matrix(q, base), axis=1, kind="stable")[:, :5])
+
+
 def test_l2_topk_large_matches_exact_slab_path(gpu, monkeypatch):
     """Stress-shaped run (65 536 x 262 144 x 256, top-10): MFMA path == exact slab path on a sample of
     queries, and the size-independent properties hold (sorted distances, unique ids, idempotent)."""
