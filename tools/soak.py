@@ -1,7 +1,7 @@
 """Soak of the concurrent paths (split RANSAC calls + pipelined rounds): the same sym_pose batch 30 times,
 every output must be identical to the single-stream reference run."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.test_gpu_post import _engine_features
 from corsair_amd import registration as R

@@ -6,7 +6,7 @@ configuration (100k clouds, 10^6 queries) would see since both stages are embarr
   python tools/stress.py [--clouds 1024] [--queries 65536] [--catalog 1000000]
 """
 import argparse, json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from corsair_amd import _lib, backend as B, engine, harness, synth
 
