@@ -217,18 +217,24 @@ void oc_rng_indices(uint64_t seed, uint64_t itr, int n, uint32_t m, int32_t* out
  * = Eigen::umeyama(src, tgt, false), called from registration_ransac_based_on_correspondence,
  * utils/eval_pose.py:95-97).  Closed form via Horn's unit quaternion: the rotation is the
  * eigenvector of the largest eigenvalue of the 4x4 matrix N built from the cross-covariance;
- * solved with 6 cyclic Jacobi sweeps (worst off-diagonal after 5: 2.5e-12 relative, after 6: converged).  Equal to the SVD/Umeyama optimum whenever that is unique.
+ * solved with 5 cyclic Jacobi sweeps (worst relative off-diagonal after 5: 2.5e-12, five orders below the
+ * f32 rounding of the stored hypothesis; after 6: round-off).  Rotation angle from h = (aqq - app) / 2 and
+ * g = apq: t = sgn(h) g / (|h| + sqrt(h^2 + g^2)), i.e. the textbook sgn(theta) / (|theta| + sqrt(theta^2
+ * + 1)) with theta = h / g without that division (h = 0 gives t = +1).  Equal to the SVD/Umeyama optimum
+ * whenever that is unique.
  * ---------------------------------------------------------------------------------------- */
 static void oc_jacobi4(double a[4][4], double v[4][4]) {
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 6; ++sweep)
+  for (int sweep = 0; sweep < 5; ++sweep)
     for (int p = 0; p < 3; ++p)
       for (int q = p + 1; q < 4; ++q) {
         const double apq = a[p][q];
         if (apq == 0.0) continue;
-        const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double h = 0.5 * (a[q][q] - a[p][p]);
+        const double den = fabs(h) + sqrt(h * h + apq * apq);
+        const double sg = (h == 0.0 || ((h > 0.0) == (apq > 0.0))) ? 1.0 : -1.0;
+        const double t = den > 0.0 ? sg * fabs(apq) / den : sg;
         const double c = 1.0 / sqrt(t * t + 1.0);
         const double s = t * c;
         a[p][p] = a[p][p] - t * apq;
