@@ -1358,7 +1358,10 @@ __global__ void k_tkf_verify(const unsigned long long* __restrict__ carry_d, int
   for (int j = 0; j < nlane; ++j) t = fminf(t, tau[q * nlane + j]);
   const double dk = __longlong_as_double((long long)carry_d[q * k + k - 1]);   // exact k-th squared distance
   const double eps = (double)(3 * d + 4) * 2.384185791015625e-07 * (qn[q] + (double)__uint_as_float(*xmax_bits));
-  const bool ok = dk - qn[q] < (double)t - eps;   // false for NaN / missing candidates
+  // f16 range: |x| and |-2 q| below 2e4 keep every hi part (and every product sum) finite; anything larger
+  // (or not finite) cannot be trusted and takes the f64 path
+  const bool in_range = __uint_as_float(*xmax_bits) < 4.0e8f && qn[q] < 1.0e8;
+  const bool ok = in_range && dk - qn[q] < (double)t - eps;   // false for NaN / missing candidates
   if (!ok) flagged[atomicAdd(n_flagged, 1)] = (int)q;
 }
 

@@ -406,6 +406,12 @@ def test_l2_topk_f16_falls_back_on_ties_and_scales(gpu, oracle_native, monkeypat
     assert want[0].tolist() == [17, 1500, 1501, 1502, 1503]
     assert np.array_equal(idx.cpu().numpy(), want)
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
+    # descriptors beyond the f16 range: nothing is trusted, everything is recomputed
+    big = (base * np.float32(3000.0)).astype(np.float32)
+    _topk_stats(reset=True)
+    idx, _ = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(big).to(gpu), 5, True)
+    assert _topk_stats() == (50, 50)
+    assert np.array_equal(idx.cpu().numpy(), np.argsort(oracle_native.dist2_matrix(q, big), axis=1, kind="stable")[:, :5])
     # without the copies everything verifies
     _topk_stats(reset=True)
     idx, _ = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(base).to(gpu), 5, True)
