@@ -155,6 +155,9 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
 }
 
 // hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
+// RN = ransac_n when it is known at compile time (10: the reference's value; the sampled pairs then stay
+// in registers between the centroid and the covariance pass), 0 = read it from the argument
+template <int RN>
 __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     const float4* __restrict__ pair32, int it0,
                                                     int bcount, int bmax, int ransac_n,
@@ -175,32 +178,65 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
   if (pr.done || itr >= pr.est_k) return;
   const uint32_t m = (uint32_t)pr.m;
   double cs_[3] = {0, 0, 0}, ct_[3] = {0, 0, 0};
-  for (int j = 0; j < ransac_n; ++j) {
-    const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    const float4 a = pair32[2 * i], b = pair32[2 * i + 1];  // one 32-B sector
-    cs_[0] += (double)a.x;
-    cs_[1] += (double)a.y;
-    cs_[2] += (double)a.z;
-    ct_[0] += (double)a.w;
-    ct_[1] += (double)b.x;
-    ct_[2] += (double)b.y;
-  }
-  const double dn = (double)ransac_n;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    cs_[a] = cs_[a] / dn;
-    ct_[a] = ct_[a] / dn;
-  }
   double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int j = 0; j < ransac_n; ++j) {
-    const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
-    const float4 a = pair32[2 * i], b = pair32[2 * i + 1];
-    const double ds[3] = {(double)a.x - cs_[0], (double)a.y - cs_[1], (double)a.z - cs_[2]};
-    const double dt[3] = {(double)a.w - ct_[0], (double)b.x - ct_[1], (double)b.y - ct_[2]};
+  if (RN > 0) {
+    float4 pa[RN > 0 ? RN : 1];
+    float2 pb[RN > 0 ? RN : 1];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < RN; ++j) {
+      const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
+      const float4 a = pair32[2 * i], b = pair32[2 * i + 1];  // one 32-B sector
+      pa[j] = a;
+      pb[j] = make_float2(b.x, b.y);
+      cs_[0] += (double)a.x;
+      cs_[1] += (double)a.y;
+      cs_[2] += (double)a.z;
+      ct_[0] += (double)a.w;
+      ct_[1] += (double)b.x;
+      ct_[2] += (double)b.y;
+    }
+    const double dn = (double)RN;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) S[a][b] = fma(ds[a], dt[b], S[a][b]);
+    for (int a = 0; a < 3; ++a) {
+      cs_[a] = cs_[a] / dn;
+      ct_[a] = ct_[a] / dn;
+    }
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const double ds[3] = {(double)pa[j].x - cs_[0], (double)pa[j].y - cs_[1], (double)pa[j].z - cs_[2]};
+      const double dt[3] = {(double)pa[j].w - ct_[0], (double)pb[j].x - ct_[1], (double)pb[j].y - ct_[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[a][b] = fma(ds[a], dt[b], S[a][b]);
+    }
+  } else {
+    for (int j = 0; j < ransac_n; ++j) {
+      const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
+      const float4 a = pair32[2 * i], b = pair32[2 * i + 1];  // one 32-B sector
+      cs_[0] += (double)a.x;
+      cs_[1] += (double)a.y;
+      cs_[2] += (double)a.z;
+      ct_[0] += (double)a.w;
+      ct_[1] += (double)b.x;
+      ct_[2] += (double)b.y;
+    }
+    const double dn = (double)ransac_n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      cs_[a] = cs_[a] / dn;
+      ct_[a] = ct_[a] / dn;
+    }
+    for (int j = 0; j < ransac_n; ++j) {
+      const int64_t i = pr.off + rng_index(seed, (uint64_t)itr, (uint64_t)j, m);
+      const float4 a = pair32[2 * i], b = pair32[2 * i + 1];
+      const double ds[3] = {(double)a.x - cs_[0], (double)a.y - cs_[1], (double)a.z - cs_[2]};
+      const double dt[3] = {(double)a.w - ct_[0], (double)b.x - ct_[1], (double)b.y - ct_[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[a][b] = fma(ds[a], dt[b], S[a][b]);
+    }
   }
   double N[4][4], V[4][4];
   N[0][0] = S[0][0] + S[1][1] + S[2][2];
@@ -1367,8 +1403,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     {
       ProfScope prof("ransac_hyp", st);
       const int htiles = (b + 255) / 256;
-      hipLaunchKernelGGL(k_ransac_hyp, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
-                         pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
+      if (ransac_n == 10)
+        hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
+      else
+        hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
     }
     if (f.pf) {
       _Float16* A16_r = A16.p + (size_t)par * n_prob * bmax * PF_K;
