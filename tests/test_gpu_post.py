@@ -174,6 +174,24 @@ def test_ransac_bit_exact_vs_oracle(gpu, oracle_native):
     assert np.array_equal(T[3], np.eye(4, dtype=np.float32)) and inl[3] == 0
 
 
+@pytest.mark.parametrize("ransac_n", [3, 6, 17])
+def test_ransac_other_sample_sizes_bit_exact(gpu, oracle_native, ransac_n):
+    """ransac_n other than the reference's 10 (Open3D's default is 6) goes through the run-time-sized
+    sampling loop of the hypothesis kernel."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(40 + ransac_n)
+    probs = [_corr_problem(rng, m, f, pose_id=20 + i) for i, (m, f) in enumerate([(1500, 0.4), (700, 0.2), (ransac_n - 1, 0.5)])]
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+    T, inl, rmse, iters = (t.cpu().numpy() for t in B.ransac_batch(S, D, off, 0.2, ransac_n, 3000, 0.999, 5))
+    for p, (src, tgt, _) in enumerate(probs):
+        wT, winl, wrmse, wit = oracle_native.ransac(src, tgt, 0.2, ransac_n, 3000, 0.999, 5)
+        assert inl[p] == winl and iters[p] == wit, (p, inl[p], winl, iters[p], wit)
+        assert np.array_equal(T[p], wT), p
+
+
 def test_ransac_seed_changes_samples_but_not_quality(gpu):
     from corsair_amd import backend as B
 
