@@ -1360,6 +1360,15 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // built from the state one round earlier: finished problems cost a few empty workgroups.
   const char* env_ov = getenv("CS_RANSAC_OVERLAP");
   hipStream_t side = (env_ov && env_ov[0] == '0') ? nullptr : side_stream();
+  // whatever path leaves this function (an error return included), the side stream has drained before the
+  // scratch buffers go back to the pool; on the normal path it already has (the final wait on the main
+  // stream is ordered behind its events), so this costs nothing
+  struct SideDrain {
+    hipStream_t st;
+    ~SideDrain() {
+      if (st) (void)hipStreamSynchronize(st);
+    }
+  } side_drain{side};
   struct Front {
     int it0 = 0, b = 0, par = 0;
     bool pf = false, on_side = false;
