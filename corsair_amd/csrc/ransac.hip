@@ -1360,13 +1360,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // built from the state one round earlier: finished problems cost a few empty workgroups.
   const char* env_ov = getenv("CS_RANSAC_OVERLAP");
   hipStream_t side = (env_ov && env_ov[0] == '0') ? nullptr : side_stream();
-  // whatever path leaves this function (an error return included), the side stream has drained before the
-  // scratch buffers go back to the pool; on the normal path it already has (the final wait on the main
-  // stream is ordered behind its events), so this costs nothing
+  // an error return must not hand the scratch buffers back to the pool while the side stream still uses
+  // them; on the normal path the final wait on the main stream is already ordered behind its events
   struct SideDrain {
     hipStream_t st;
+    bool clean = false;
     ~SideDrain() {
-      if (st) (void)hipStreamSynchronize(st);
+      if (st && !clean) (void)hipStreamSynchronize(st);
     }
   } side_drain{side};
   struct Front {
@@ -1599,6 +1599,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                      d_probs, n_prob, (double)scale, d_T, d_inliers, d_rmse, d_iters);
   CS_LAUNCH_CHECK();
   CS_HIP_CHECK(hipStreamSynchronize(s));
+  side_drain.clean = true;
   return CS_OK;
 }
 
