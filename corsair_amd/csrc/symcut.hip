@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) void k_symcut_select(
   __syncthreads();
 
   // ---- 2. radix select of the n_sel-th smallest key ---------------------------------------
+  // The passes stop as soon as the bin of the wanted rank holds exactly the keys still needed: every key
+  // of that bin is then selected, whatever its lower digits are (typically after 4-5 of the 8 passes).
+  __shared__ int s_done;
+  int shift_final = 0;
+  if (tid == 0) s_done = 0;
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 56 - 8 * pass;
     hist[tid] = 0;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256) void k_symcut_select(
       if (here) {
         s_remaining = rem - excl;
         s_prefix = (prefix << 8) | (unsigned long long)tid;
+        if (excl + hv == rem) s_done = 1;  // the whole bin is selected
       }
       if (tid == 0 && total < rem) {  // cannot happen (rem <= selected keys); mirror the serial fallback
         s_remaining = rem - (total - hist[255]);
@@ -211,9 +217,13 @@ __global__ __launch_bounds__(256) void k_symcut_select(
       }
     }
     __syncthreads();
+    shift_final = shift;
+    if (s_done) break;
   }
-  const unsigned long long kth = s_prefix;  // value of the n_sel-th smallest key
-  const int need_eq = s_remaining;          // how many keys == kth belong to the selection
+  // selection = keys whose leading digits (key >> shift_final) are below the prefix, plus the first
+  // need_eq (in row order) of those equal to it; after all 8 passes shift_final = 0: the exact k-th key
+  const unsigned long long kth = s_prefix;
+  const int need_eq = s_remaining;
 
   // ordered compaction (ascending row).  Each wave owns a contiguous quarter of the rows and walks it 64
   // rows at a time (coalesced key reads; ranks inside a step come from ballots): a counting pass, one
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void k_symcut_select(
     int n_lt = 0, n_eq = 0;
     for (int i = w0; i < w1; i += 64) {
       const bool in = i + lane < w1;
-      const unsigned long long key = in ? keys[i + lane] : ~0ULL;
+      const unsigned long long key = in ? keys[i + lane] >> shift_final : ~0ULL;
       n_lt += __popcll(__ballot(in && key < kth));
       n_eq += __popcll(__ballot(in && key == kth));
     }
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void k_symcut_select(
     }
     for (int i = w0; i < w1; i += 64) {
       const bool in = i + lane < w1;
-      const unsigned long long key = in ? keys[i + lane] : ~0ULL;
+      const unsigned long long key = in ? keys[i + lane] >> shift_final : ~0ULL;
       const bool lt = in && key < kth, eq = in && key == kth;
       const unsigned long long eqm = __ballot(eq);
       const bool take = lt || (eq && eq_rank + __popcll(eqm & below) < need_eq);
