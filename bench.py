@@ -1,21 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- end-to-end queries/sec (embed + retrieve + register) of the CORSAIR hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): Scan2CAD-chair-sized synthetic evaluation -- catalog of 652
-CAD clouds, queries = posed re-samplings of catalog clouds, 10 000 points @ voxel 0.03, random-init
-ResUNetBN2C + embedding weights (the reference checkpoints / ScanNet data are not available).
-A step = one batch of 32 queries through: GPU voxelise -> sparse ResUNet forward -> global descriptor
--> exact top-k against the catalog descriptors -> symmetry-aided registration against the top-1 CAD
-(feature 5-NN, part cut, K(+4) part hypotheses, batched RANSAC 100 000 x ransac_n 10, Chamfer).
-The raw query clouds and the embedded catalog are resident in HBM before the timed region.
+Workloads (BASELINE.json `configs`), selected with --workload:
 
-One process per GPU (torch.distributed / RCCL): the catalog is embedded in shards and all-gathered
-once (setup, reported as catalog_embed_s), queries are sharded with a fixed per-GPU count ("weak").
-Prints ONE JSON line on rank 0.
+  chair  (default, configs[1]) Scan2CAD-chair-sized synthetic evaluation: catalog of 652 CAD clouds, query
+         pool 993, labels 650 x sym 1 + 2 x sym 4, 10 000 points @ voxel 0.03.
+  table  (configs[2]) Scan2CAD-table-sized: catalog 830, query pool 291, symmetry labels with the
+         histogram of configs/04379243_scan2cad_rot_sym_label.txt (233 x 1, 422 x 2, 7 x 3, 128 x 4,
+         40 x 12): 72 % of the CADs take the K = 4 + mirror path (9 RANSACs per query instead of 3).
+  stress (configs[4]) batch-64 sparse ResUNet forward on 15 000-point clouds @ 2 cm voxels + descriptor
+         top-10 against a 10^6 catalog; a step = 1024 clouds (16 batches) + their share of the
+         10^6 x 10^6 top-10 (10 240 queries).
+
+chair / table: a step = one batch of 32 queries through GPU voxelise -> sparse ResUNet forward -> global
+descriptor -> exact top-1 against the catalog descriptors -> symmetry-aided registration against the
+top-1 CAD (feature 5-NN, part cut, K(+4) part hypotheses, batched RANSAC 100 000 x ransac_n 10,
+Chamfer).  Random-init ResUNetBN2C + embedding weights (the reference checkpoints / ScanNet data are
+not available).  Raw query clouds and the embedded catalog are resident in HBM before the timed region.
+
+--gpus N: one process per GPU (torch.distributed, backend "nccl" = RCCL).  Under torchrun
+(WORLD_SIZE set) this process is one rank; started plainly with --gpus N > 1 it launches the N ranks as
+a child `python -m torch.distributed.run` BEFORE anything touches the GPU and exits with its code.
+configs[3] is `--gpus 8 --workload chair` / `table`: the catalog is embedded in voxel-count-balanced
+shards and all-gathered once (setup, reported as catalog_embed_s); queries are sharded with a fixed
+per-GPU count ("weak"); the timed region contains no collective.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -30,8 +44,16 @@ F32_PEAK_TFLOPS = 157.3   # MI355X f32: matrix (v_mfma_f32_32x32x2_f32) == vecto
 F64_PEAK_TFLOPS = 78.6
 F16_PEAK_TFLOPS = 2516.6  # dense f16/bf16 MFMA: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (16x the f32 matrix rate)
 BATCH = 32
-N_CATALOG = 652
-N_QUERY_POOL = 993
+
+# label -> count; table: histogram of the reference's configs/04379243_scan2cad_rot_sym_label.txt
+# (SURVEY 2 #28), chair: configs/03001627_scan2cad_rot_sym_label.txt
+SYM_HISTOGRAM = {"chair": {1: 650, 4: 2}, "table": {1: 233, 2: 422, 3: 7, 4: 128, 12: 40}}
+QUERY_POOL = {"chair": 993, "table": 291}
+FAMILIES = ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap")
+KERNEL_OF = {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_count", "ransac_pre": "k_ransac_prefilter",
+             "knn": "k_knn_f16", "chamfer": "k_chamfer_mfma", "topk": "k_topk_f16"}
+PEAK_OF = {"knn": F16_PEAK_TFLOPS, "chamfer": F64_PEAK_TFLOPS, "ransac_pre": F16_PEAK_TFLOPS,
+           "topk": F16_PEAK_TFLOPS}
 
 
 def parse():
@@ -39,9 +61,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=("chair", "table", "stress"), default="chair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="queries in the CPU baseline sample")
-    ap.add_argument("--catalog", type=int, default=N_CATALOG)
+    ap.add_argument("--cpu-sample", type=int, default=6,
+                    help="most queries in the CPU baseline sample (SURVEY 8d's full shape: 32)")
+    ap.add_argument("--cpu-problems", type=int, default=12,
+                    help="the CPU sample stops once it has run this many RANSAC problems (~1.9 s each on 16 cores)")
+    ap.add_argument("--cpu-catalog", type=int, default=64,
+                    help="catalog subset the CPU baseline retrieves against (SURVEY 8d: 64)")
+    ap.add_argument("--catalog", type=int, default=0, help="catalog size (default: the workload's)")
+    ap.add_argument("--desc-dim", type=int, default=256, help="stress: descriptor width (256 or 512)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="query batches in flight in the timed region (host threads x HIP streams)")
     ap.add_argument("--no-solo-probe", action="store_true",
@@ -51,71 +80,193 @@ def parse():
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
+def maybe_self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as a CHILD process (never an exec,
+    and before this process has made any HIP call) and leave with its return code."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; refusing to report a mislabelled run\n"
+                             % (args.gpus, ws))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import torch  # device_count() does not create a HIP context
 
-    from corsair_amd import _lib, harness, registration, sharding, synth
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and "CORSAIR_DIST_BACKEND" not in env:
+        # rehearsal on a box with fewer devices than ranks: ranks share devices, RCCL cannot (it needs
+        # one device per rank), so the exchange runs over gloo; the JSON line says so
+        sys.stderr.write("[bench] %d ranks on %d visible device(s): ranks share devices, backend gloo\n"
+                         % (args.gpus, n_dev))
+        env["CORSAIR_DIST_BACKEND"] = "gloo"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
-    _lib.require_gpu()
-    # one process per GPU; CORSAIR_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
-    # N > 1 code path on a single-GPU box (RCCL needs distinct devices)
-    backend = os.environ.get("CORSAIR_DIST_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+class Ctx:
+    """What a workload needs from the process: rank layout, device, the one dist handle, logging."""
 
-    cfg = harness.Config()
-    sd, emb = synth.make_state_dicts(cfg.random_seed)
-    pipe = harness.Pipeline(sd, emb, device=dev, config=cfg)
+    def __init__(self, args):
+        import torch
 
-    # ---- setup: catalog (sharded embed + all-gather) and this rank's query clouds -------------------
-    C = args.catalog
-    my_cat = sharding.shard_ids(C, rank, world)
-    n_q = (args.warmup + args.steps) * BATCH
-    q_ids = [(rank * n_q + i) % N_QUERY_POOL for i in range(n_q)]
-    t0 = time.time()
-    cat_clouds = [synth.make_cloud(c, 15000)[: cfg.n_points] for c in my_cat]
-    torch.cuda.synchronize()
-    t1 = time.time()
-    cat_local = pipe.embed_clouds(cat_clouds)
-    torch.cuda.synchronize()
-    # the one exchange of the path: RCCL all-gather of the embedded catalog shards over xGMI
-    catalog = sharding.gather_catalog(dist, cat_local, C, world)
-    torch.cuda.synchronize()
-    catalog_embed_s = time.time() - t1
-    sym = np.ones(C, np.int32)
-    sym[::326] = 4
+        from corsair_amd import _lib
 
-    q_clouds, q_T, q_cad = [], [], []
-    for q in q_ids:
-        cad = q % C
-        T = synth.random_pose(q, max_trans=0.0)
-        pc = synth.make_cloud(cad, 15000)[15000 - cfg.n_points:]
-        q_clouds.append(synth.apply_pose(pc, T))
-        q_T.append(T)
-        q_cad.append(cad)
-    q_dev, q_off = [], []
-    for b in range(args.warmup + args.steps):
-        chunk = q_clouds[b * BATCH:(b + 1) * BATCH]
-        q_dev.append(torch.from_numpy(np.concatenate(chunk, 0)).to(dev))
-        q_off.append(np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist())
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        _lib.require_gpu()
+        # one process per GPU; CORSAIR_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
+        # N > 1 code path on a single-GPU box (RCCL needs distinct devices)
+        self.backend = os.environ.get("CORSAIR_DIST_BACKEND", "nccl")
+        self.n_devices = torch.cuda.device_count()
+        self.dev_index = local_rank % self.n_devices
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
 
-    results = []
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
 
-    def step(b):
-        qs = pipe.embed_batch(q_dev[b], q_off[b])
+    def log(self, msg):
+        if self.rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    def barrier(self):
+        import torch
+
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(self, vals):
+        """max over ranks of a list of floats (host list in, host list out)."""
+        import torch
+
+        if self.dist is None:
+            return list(vals)
+        t = torch.tensor(vals, device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def gather_floats(self, vals):
+        """[world, len(vals)] array of every rank's values (on every rank)."""
+        import torch
+
+        if self.dist is None:
+            return np.asarray([vals], dtype=np.float64)
+        t = torch.tensor(vals, device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return torch.stack(out).cpu().numpy()
+
+
+def sym_labels(kind, n):
+    """Per-CAD symmetry labels with the label histogram of the reference's label file, dealt to catalog
+    ids by a seeded permutation (scaled when --catalog differs from the real size)."""
+    hist = SYM_HISTOGRAM[kind]
+    total = sum(hist.values())
+    labels = np.concatenate([np.full(c, l, np.int32) for l, c in sorted(hist.items())])
+    if n != total:
+        labels = labels[(np.arange(n) * total) // max(n, 1)] if n < total else np.resize(labels, n)
+    rng = np.random.Generator(np.random.Philox(key=0x5A1B, counter=n))
+    return labels[rng.permutation(n)]
+
+
+# =====================================================================================================
+class RegistrationWorkload:
+    """configs[1] (chair) / configs[2] (table): embed + retrieve + register, 32 queries per step."""
+
+    def __init__(self, ctx, kind):
+        from corsair_amd import harness, synth
+
+        self.ctx, self.kind = ctx, kind
+        self.cfg = harness.Config()
+        self.C = ctx.args.catalog or sum(SYM_HISTOGRAM[kind].values())
+        self.pool = QUERY_POOL[kind]
+        self.sd, self.emb = synth.make_state_dicts(self.cfg.random_seed)
+        self.pipe = harness.Pipeline(self.sd, self.emb, device=ctx.dev, config=self.cfg)
+        self.sym = sym_labels(kind, self.C)
+        self.results = []
+        self.units_per_step = BATCH
+
+    def setup(self):
+        import torch
+
+        from corsair_amd import backend as B, sharding, synth
+
+        ctx, cfg, C = self.ctx, self.cfg, self.C
+        args = ctx.args
+        # ---- catalog: voxel-count pre-pass on an interleaved slice, balanced shards, embed, all-gather ----
+        t1 = time.time()
+        mine = sharding.shard_ids(C, ctx.rank, ctx.world)
+        clouds = {c: synth.make_cloud(c, 15000)[: cfg.n_points] for c in mine}
+        counts = []
+        for i in range(0, len(mine), 64):
+            chunk = [clouds[c] for c in mine[i:i + 64]]
+            off = np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist()
+            _, _, out_off = B.voxelize(torch.from_numpy(np.concatenate(chunk, 0)).to(ctx.dev), off, cfg.voxel_size)
+            counts += list(np.diff(out_off))
+        vox = sharding.all_gather_counts(ctx.dist, mine, counts, C, ctx.world)
+        shards = sharding.balanced_shards(vox, ctx.world)
+        self.balance = {"catalog_voxels_max_over_mean_balanced": sharding.imbalance(vox, shards),
+                        "catalog_voxels_max_over_mean_interleaved": sharding.imbalance(
+                            vox, [sharding.shard_ids(C, r, ctx.world) for r in range(ctx.world)])}
+        my_cat = shards[ctx.rank]
+        cat_clouds = [clouds[c] if c in clouds else synth.make_cloud(c, 15000)[: cfg.n_points] for c in my_cat]
+        torch.cuda.synchronize()
+        t2 = time.time()
+        cat_local = self.pipe.embed_clouds(cat_clouds)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        # the one exchange of the path: RCCL all-gather of the embedded catalog shards over xGMI
+        self.catalog = sharding.gather_catalog(ctx.dist, cat_local, C, ctx.world, shards)
+        torch.cuda.synchronize()
+        t4 = time.time()
+        self.catalog_embed_s = t4 - t2
+        per_rank = ctx.gather_floats([t3 - t2, t4 - t3])
+        self.balance["catalog_embed_s_per_rank"] = [round(float(v), 4) for v in per_rank[:, 0]]
+        self.balance["catalog_all_gather_s"] = round(float(per_rank[:, 1].max()), 4)
+        self.balance["catalog_prepass_s"] = round(t2 - t1, 3)
+
+        # ---- this rank's queries: posed re-samplings of catalog clouds (known GT pose) ----------------
+        n_b = args.warmup + args.steps
+        self.n_q = n_b * BATCH
+        self.q_ids = [(ctx.rank * self.n_q + i) % self.pool for i in range(self.n_q)]
+        self.q_clouds, self.q_T, self.q_cad = [], [], []
+        for q in self.q_ids:
+            cad = q % C
+            T = synth.random_pose(q, max_trans=0.0)
+            pc = synth.make_cloud(cad, 15000)[15000 - cfg.n_points:]
+            self.q_clouds.append(synth.apply_pose(pc, T))
+            self.q_T.append(T)
+            self.q_cad.append(cad)
+        self.q_dev, self.q_off = [], []
+        for b in range(n_b):
+            chunk = self.q_clouds[b * BATCH:(b + 1) * BATCH]
+            self.q_dev.append(torch.from_numpy(np.concatenate(chunk, 0)).to(ctx.dev))
+            self.q_off.append(np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist())
+        ctx.log("setup done: %s catalog %d clouds embedded in %.2fs, %d query batches resident"
+                % (self.kind, C, self.catalog_embed_s, n_b))
+
+    def step(self, b):
+        from corsair_amd import _lib, registration
+
+        pipe, catalog, rank, n_q = self.pipe, self.catalog, self.ctx.rank, self.n_q
+        qs = pipe.embed_batch(self.q_dev[b], self.q_off[b])
         ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
         # host work that only needs the voxel counts goes here, while the convolutions are still running
         q_anc = [registration.draw_anchors(qs.offsets[i + 1] - qs.offsets[i], 100, ids[i][0]) for i in range(BATCH)]
@@ -126,40 +277,305 @@ def main():
         # passes, which would drop the K symmetric hypotheses -- 2/3 of the registration work -- from
         # the timed region.  The bench accepts the best-balanced anchor so every query runs
         # 1 + K (+4) RANSACs like the reference workload.  Parity tests use the real gate.
-        res = pipe.register(qs, cads, sym[top], anchor_ids=ids, force_gate=True, query_anchors=q_anc)
+        res = pipe.register(qs, cads, self.sym[top], anchor_ids=ids, force_gate=True, query_anchors=q_anc)
         Tb, Tr, cdb, its = _lib.to_host(res.T_best, res.T_ransac, res.cd_best, res.iters)
-        results.append((b, top, Tb, Tr, cdb, res.ok, its, res.n_problems))
+        self.results.append((b, top, Tb, Tr, cdb, res.ok, its, res.n_problems))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def same_results(self, a, b):
+        return np.array_equal(a[2], b[2]) and np.array_equal(a[6], b[6])
+
+    def solo_env(self):
+        return {"CS_RANSAC_OVERLAP": "0", "CORSAIR_SPLIT_RANSAC": "0"}
+
+    def config(self, steps):
+        from corsair_amd import harness
+
+        t_l, r_l, hits, iters_all, nprob = [], [], 0, [], 0
+        for b, top, Tb, Tr, cdb, ok, iters, n_problems in self.results:
+            for i in range(BATCH):
+                qi = b * BATCH + i
+                t, r = harness.eval_pose(Tb[i], self.q_T[qi], np.eye(4), int(self.sym[top[i]]))
+                t_l.append(t)
+                r_l.append(r)
+                hits += int(top[i] == self.q_cad[qi])
+            iters_all.append(iters)
+            nprob += n_problems
+        agg = harness.aggregate(r_l, t_l)
+        iters_all = np.concatenate(iters_all)
+        idx = {"chair": 1, "table": 2}[self.kind]
+        hist = ", ".join("%d x sym %d" % (int((self.sym == l).sum()), l) for l in np.unique(self.sym))
+        return {"workload": "configs[%d]: single-MI355X Scan2CAD %s eval shape (C=%d catalog [%s], query pool %d, "
+                            "32 queries/step, 10k pts @ voxel 0.03, ResUNetBN2C+embedding random init, "
+                            "top-1 retrieval, sym_pose RANSAC 100000x10)" % (idx, self.kind, self.C, hist, self.pool),
+                "queries_per_step": BATCH, "catalog": self.C, "catalog_embed_s": self.catalog_embed_s,
+                "ransac_problems_per_query": nprob / (steps * BATCH),
+                "ransac_mean_iters": float(iters_all.mean()),
+                "top1_hit_rate": hits / (steps * BATCH),
+                "rre_mean_deg": agg["rre_mean_deg"], "rre_15": agg["rre_15"]}
+
+    def extras(self, out):
+        import ctypes
+
+        from corsair_amd import _lib
+
+        st = (ctypes.c_uint64 * 5)()
+        _lib.load().cs_ransac_prefilter_stats(st, 0)
+        out["ransac_prefilter"] = {"survivors": int(st[3]), "hypotheses": int(st[4]),
+                                   "note": "hypotheses whose f16 upper bound reached the best count and were "
+                                           "recounted exactly / all hypotheses evaluated (whole run incl. warmup)"}
+        out["shard_balance"] = self.balance
+
+    def cpu_baseline(self):
+        """The CPU oracle (kind "port": the build's restatement of the reference CPU path, OpenMP over
+        independent rows / registrations) timed on a bounded sample of the same workload: the first
+        `cpu_sample` queries of the first timed step -- embed, retrieve against a `cpu_catalog`-item
+        subset of the same catalog descriptors (SURVEY 8d's C1 shape is 32 queries x 64 items) and
+        register against the top-1 CAD."""
+        from corsair_amd import registration as R
+        from oracle import native, post, resunet as oref, sparse as osp
+
+        args, cfg, catalog, sym = self.ctx.args, self.cfg, self.catalog, self.sym
+        native.load()
+        n = min(args.cpu_sample, BATCH * args.steps)
+        nc = min(args.cpu_catalog, self.C)
+        first = args.warmup * BATCH
+        clouds = self.q_clouds[first:first + n]
+        cat_desc = catalog.desc[:nc].cpu().numpy()
+        off = catalog.offsets
+        cat_F = catalog.F[: off[nc]].cpu().numpy()
+        cat_X = catalog.origin[: off[nc]].cpu().numpy()
+        t0 = time.time()
+        grids, origins = [], []
+        for pc in clouds:
+            xyz, grid, _ = osp.quantize_cloud(pc, cfg.voxel_size)
+            grids.append(grid)
+            origins.append(xyz)
+        coords = osp.sparse_collate(grids)
+        feats = np.ones((coords.shape[0], 1), np.float32)
+        out, feat8, maps = oref.resunet_forward(self.sd, coords, feats)
+        desc = oref.embedding_forward(self.emb, feat8, maps["c8"][:, 0], n)
+        t_embed = time.time() - t0
+        rank_, _ = post.retrieval_rank(desc, cat_desc)
+        top = rank_[:, 0]
+        t_ret = time.time() - t0 - t_embed
+        qoff = np.concatenate([[0], np.cumsum([len(g) for g in grids])])
+        nprob = done = 0
+        for i in range(n):
+            if nprob >= args.cpu_problems:     # bounded sample: ~10-30 s of CPU work
+                break
+            done += 1
+            F0, x0 = out[qoff[i]:qoff[i + 1]], origins[i]
+            c = int(top[i])
+            F1, x1 = cat_F[off[c]:off[c + 1]], cat_X[off[c]:off[c + 1]]
+            gq = first + i
+            a0 = R.draw_anchors(len(F0), 100, 2 * gq)
+            a1 = R.draw_anchors(len(F1), 100, 2 * gq + 1)
+            post.sym_pose(F0, x0, F1, x1, int(sym[c]), cfg.k_nn, cfg.max_corr, 0, a0, a1,
+                          cfg.ransac_max_iter, cfg.ransac_confidence, force_gate=True)
+            nprob += 1 + len(R.part_configs(4 if sym[c] >= 2 else 2, int(sym[c])))
+        total = time.time() - t0
+        t_reg = total - t_embed - t_ret
+        per_query = (t_embed + t_ret) / n + t_reg / done
+        return {"value": 1.0 / per_query, "unit": "queries/s", "cores": native.num_threads(), "kind": "port",
+                "sample": "queries of the first timed step against a %d-item catalog subset (SURVEY 8d C1 shape "
+                          "is 32 x 64; the per-query cost does not depend on the subset size beyond the "
+                          "retrieval term, so the rate extrapolates linearly): oracle embed of %d queries "
+                          "%.2fs + retrieve %.3fs + sym_pose of the first %d of them %.2fs (%d RANSAC "
+                          "problems of 100000 iterations); value = 1 / (embed+retrieve per query + "
+                          "sym_pose per query)" % (nc, n, t_embed, t_ret, done, t_reg, nprob)}
+
+
+# =====================================================================================================
+class StressWorkload:
+    """configs[4]: batch-64 forward on 15k-pt clouds @ 2 cm + top-10 against a 10^6-descriptor catalog.
+    One step = 16 forward batches (1024 clouds) + the proportional slice of the 10^6 x 10^6 top-10
+    (1024 / 100 000 of 10^6 queries = 10 240 queries)."""
+    FWD_BATCH = 64
+    BATCHES_PER_STEP = 16
+    TOPK_PER_STEP = 10240
+    N_UNIQUE = 256
+
+    def __init__(self, ctx):
+        from corsair_amd import harness, synth
+
+        self.ctx = ctx
+        self.cfg = harness.Config(voxel_size=0.02, n_points=15000, batch_size=self.FWD_BATCH)
+        self.sd, self.emb = synth.make_state_dicts(31)
+        self.pipe = harness.Pipeline(self.sd, self.emb, device=ctx.dev, config=self.cfg)
+        self.C = ctx.args.catalog or 1000000
+        self.d = ctx.args.desc_dim
+        self.units_per_step = self.FWD_BATCH * self.BATCHES_PER_STEP
+        self.results = []
+        self.voxels = 0
+        self.clouds = 0
+
+    def setup(self):
+        import torch
+
+        from corsair_amd import synth
+
+        ctx = self.ctx
+        t0 = time.time()
+        base = ctx.rank * self.N_UNIQUE
+        clouds = [synth.make_cloud(base + c, 15000) for c in range(self.N_UNIQUE)]
+        self.batches = []
+        for b in range(0, self.N_UNIQUE, self.FWD_BATCH):
+            chunk = clouds[b:b + self.FWD_BATCH]
+            self.batches.append((torch.from_numpy(np.concatenate(chunk)).to(ctx.dev),
+                                 np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist()))
+        self.cloud_sample = clouds[:2]
+        # descriptors: Philox standard normal, row-normalised (SURVEY 8d); generated in slabs
+        self.x = torch.empty((self.C, self.d), dtype=torch.float32, device=ctx.dev)
+        for i, s in enumerate(range(0, self.C, 131072)):
+            n = min(131072, self.C - s)
+            self.x[s:s + n] = torch.from_numpy(synth.make_descriptors(n, self.d, seed=4321 + i)).to(ctx.dev)
+        nq = 65536
+        self.q = torch.from_numpy(synth.make_descriptors(nq, self.d, seed=1234 + ctx.rank)).to(ctx.dev)
         torch.cuda.synchronize()
+        ctx.log("setup done: stress, %d clouds resident, catalog %d x %d in %.1fs" % (self.N_UNIQUE, self.C, self.d,
+                                                                                  time.time() - t0))
 
-    def log(msg):
-        if rank == 0:
-            print("[bench] " + msg, file=sys.stderr, flush=True)
+    def step(self, b):
+        from corsair_amd import backend as B
 
-    log("setup done: catalog %d clouds embedded in %.2fs, %d query batches resident" %
-        (C, catalog_embed_s, len(q_dev)))
+        last = None
+        for j in range(self.BATCHES_PER_STEP):
+            xyz, off = self.batches[(b * self.BATCHES_PER_STEP + j) % len(self.batches)]
+            last = self.pipe.embed_batch(xyz, off)
+            self.voxels += last.F.shape[0]
+            self.clouds += len(off) - 1
+        s = (b * self.TOPK_PER_STEP) % (self.q.shape[0] - self.TOPK_PER_STEP + 1)
+        idx = B.l2_topk(self.q[s:s + self.TOPK_PER_STEP], self.x, 10)
+        self.results.append((b, idx[:64].cpu().numpy(), last.desc[:4].cpu().numpy()))
+
+    def same_results(self, a, b):
+        return np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+    def solo_env(self):
+        return None
+
+    def config(self, steps):
+        import ctypes
+
+        from corsair_amd import _lib
+
+        st = (ctypes.c_uint64 * 2)()
+        _lib.load().cs_l2_topk_stats(st, 0)
+        return {"workload": "configs[4]: synthetic stress -- batch-64 sparse ResUNetBN2C forward + embedding on "
+                            "15k-pt clouds @ 2 cm voxels, and top-10 of %d-d descriptors against a %d catalog; "
+                            "one step = 1024 clouds (16 batches) + 10240 top-10 queries (the clouds' share of "
+                            "10^6 x 10^6); a 'query' here = one cloud embedded + its 10 top-10 look-ups"
+                            % (self.d, self.C),
+                "queries_per_step": self.units_per_step, "catalog": self.C, "desc_dim": self.d,
+                "voxels_per_cloud": self.voxels / max(self.clouds, 1),
+                "topk_f16_shortlist_queries": int(st[0]), "topk_recomputed_by_f64_path": int(st[1])}
+
+    def extras(self, out):
+        pass
+
+    def cpu_baseline(self):
+        """Oracle forward + embedding of a 2-cloud batch and oracle top-10 of 32 queries against the
+        first 131 072 catalog rows, scaled to the step's mix (1 cloud : 10 look-ups against C rows)."""
+        from oracle import native, resunet as oref, sparse as osp
+
+        native.load()
+        t0 = time.time()
+        grids = [osp.quantize_cloud(pc, self.cfg.voxel_size)[1] for pc in self.cloud_sample]
+        coords = osp.sparse_collate(grids)
+        feats = np.ones((coords.shape[0], 1), np.float32)
+        out, feat8, maps = oref.resunet_forward(self.sd, coords, feats)
+        oref.embedding_forward(self.emb, feat8, maps["c8"][:, 0], len(grids))
+        t_fwd = (time.time() - t0) / len(grids)
+        nq, nx = 32, min(131072, self.C)
+        q = self.q[:nq].cpu().numpy()
+        x = self.x[:nx].cpu().numpy()
+        t1 = time.time()
+        d2 = native.dist2_matrix(q, x)
+        np.argsort(d2, axis=1, kind="stable")[:, :10]
+        t_top = (time.time() - t1) / nq * (self.C / nx)
+        per_cloud = t_fwd + 10 * t_top
+        return {"value": 1.0 / per_cloud, "unit": "queries/s", "cores": native.num_threads(), "kind": "port",
+                "sample": "oracle forward+embedding of a 2-cloud batch (%.2fs per cloud) + exact f64 top-10 of %d "
+                          "queries against %d rows scaled to %d rows (%.3fs per look-up); one 'query' = 1 cloud "
+                          "+ 10 look-ups" % (t_fwd, nq, nx, self.C, t_top)}
+
+
+# =====================================================================================================
+def roofline_of(fam, solo, args):
+    """Roofline object for the dominant kernel family of the timed region.  `achieved` follows SURVEY
+    8d's algorithmic units: 30 FLOP per (hypothesis, pair) for the RANSAC inlier count -- whichever
+    kernel evaluates it --, 2 pairs Cin Cout for the convolutions, 2 Q C d for the top-k."""
+    dom = max(KERNEL_OF, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    peak = PEAK_OF.get(dom, F32_PEAK_TFLOPS)
+    n = max(d["launches"], 1)
+    achieved = d["flop"] / (max(d["ms"], 1e-9) * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+         "frac": achieved / peak, "traffic": None, "avg_launch_ms": d["ms"] / n, "launches": d["launches"],
+         "flop_per_launch": d["flop"] / n, "concurrent": dom == "ransac_pre",
+         "units": {"ransac_pre": "30 FLOP per (hypothesis, pair) (SURVEY 8d), peak = dense f16 MFMA",
+                   "ransac_eval": "30 FLOP per (hypothesis, pair) (SURVEY 8d), peak = f32 MFMA",
+                   "conv": "2 x pairs x Cin x Cout (SURVEY 8d), peak = f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                   "topk": "2 Q C d (SURVEY 8d), peak = dense f16 MFMA",
+                   "knn": "2 N0 N1 16 (SURVEY 8d), peak = dense f16 MFMA",
+                   "chamfer": "8 N0 N1, peak = f64 MFMA"}[dom]}
+    if dom == "ransac_pre":
+        # the matrix pipe executes 32 f16 multiply-adds per (hypothesis, pair): a_hi (b_hi + b_lo)
+        r["achieved_executed"] = achieved * 64.0 / 30.0
+        r["frac_executed"] = r["achieved_executed"] / peak
+        if solo and solo["launches"]:
+            a_solo = solo["flop"] / (solo["ms"] * 1e-3) / 1e12
+            r["solo"] = {"achieved": a_solo, "frac": a_solo / peak, "frac_executed": a_solo * 64.0 / 30.0 / peak,
+                         "avg_launch_ms": solo["ms"] / solo["launches"], "launches": solo["launches"],
+                         "note": "same kernel and inputs with CS_RANSAC_OVERLAP=0 CORSAIR_SPLIT_RANSAC=0 "
+                                 "(nothing else on the GPU while it runs), extra untimed pass"}
+    if dom == "topk":
+        r["achieved_executed"] = achieved * 3.0   # x_hi q_hi + x_lo q_hi + x_hi q_lo
+        r["frac_executed"] = r["achieved_executed"] / peak
+    # HBM bytes per launch and SQ pipe-busy fractions of the dominant kernel from separate rocprofv3 --pmc
+    # runs of this same command (summaries committed under profiles/)
+    tpath = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("kernel") == r["kernel"]:
+            r["traffic"] = tj.get("hbm_bytes_per_launch")
+            for k in ("mfma_busy", "valu_active", "wait_any", "source"):
+                if k in tj:
+                    r[k if k != "source" else "counters_source"] = tj[k]
+    return r
+
+
+def main():
+    args = parse()
+    maybe_self_launch(args)
+    import torch
+
+    from corsair_amd import _lib
+
+    ctx = Ctx(args)
+    wl = StressWorkload(ctx) if args.workload == "stress" else RegistrationWorkload(ctx, args.workload)
+    wl.setup()
+
     # Query batches are independent: `--pipeline D` keeps D of them in flight, each driven by its own
     # host thread on its own HIP stream, so the host work of one batch (index plumbing, the per-chunk
     # RANSAC control loop) overlaps the kernels of another.  D = 1 is the plain sequential loop.
     depth = max(1, min(args.pipeline, args.steps))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(depth, 2))]
+    streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 2))]
 
     def run_steps(first, last, depth=depth):
         if depth == 1:
             for b in range(first, last):
-                step(b)
+                wl.step(b)
             return
         errors = []
 
         def worker(w):
             try:
-                torch.cuda.set_device(dev_index)
+                torch.cuda.set_device(ctx.dev_index)
                 with torch.cuda.stream(streams[w]):
                     for b in range(first + w, last, depth):
-                        step(b)
+                        wl.step(b)
                     streams[w].synchronize()
             except BaseException as e:  # surface worker failures in the main thread
                 errors.append(e)
@@ -173,19 +589,21 @@ def main():
             raise errors[0]
 
     run_steps(0, args.warmup)
-    log("warmup done")
-    results.clear()
+    ctx.log("warmup done")
+    wl.results.clear()
     _lib.prof_enable(True)
     _lib.prof_reset()
-    barrier()
+    ctx.barrier()
     t_start = time.time()
     run_steps(args.warmup, args.warmup + args.steps)
-    barrier()
+    torch.cuda.synchronize()
+    own_elapsed = time.time() - t_start
+    ctx.barrier()
     elapsed = time.time() - t_start
     _lib.prof_enable(False)
-    log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
+    ctx.log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
     fam = {}
-    for name in ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap"):
+    for name in FAMILIES:
         ms, n, units = _lib.prof_get(name)
         fam[name] = {"ms": ms, "launches": n, "flop": units}
     # In the timed region the prefilter launches of a step overlap other work (the vanilla and the
@@ -194,12 +612,12 @@ def main():
     # A short extra pass with both overlaps switched off gives the kernel's stand-alone rate (same inputs,
     # same launches merged back into one call); reported as roofline.solo, not used for `value`.
     solo = None
-    if world == 1 and not args.no_solo_probe and args.steps >= 1:
-        saved = {k: os.environ.get(k) for k in ("CS_RANSAC_OVERLAP", "CORSAIR_SPLIT_RANSAC")}
-        os.environ["CS_RANSAC_OVERLAP"] = "0"
-        os.environ["CORSAIR_SPLIT_RANSAC"] = "0"
+    if ctx.world == 1 and not args.no_solo_probe and args.steps >= 1 and wl.solo_env():
+        env = wl.solo_env()
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
-            keep = list(results)
+            keep = list(wl.results)
             _lib.prof_reset()
             _lib.prof_enable(True)
             run_steps(args.warmup, args.warmup + min(2, args.steps), depth=1)
@@ -207,94 +625,47 @@ def main():
             _lib.prof_enable(False)
             ms, n, units = _lib.prof_get("ransac_pre")
             solo = {"ms": ms, "launches": n, "flop": units}
-            results[:] = keep
+            wl.results[:] = keep
         finally:
             for k, v in saved.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        log("stand-alone prefilter pass done")
+        ctx.log("stand-alone prefilter pass done")
     # Throughput mode, reported next to the contract number (never instead of it): the same K batches
     # again with two of them in flight.  Kernels of the two streams share the GPU, so per-launch event
-    # times are not a roofline measurement there; profiling stays off.  The poses must come out
+    # times are not a roofline measurement there; profiling stays off.  The results must come out
     # identical to the sequential pass.
     overlap = None
     if depth == 1 and args.steps >= 2 and not args.no_overlap_probe:
-        seq_results = {r[0]: r for r in results}
-        results.clear()
-        barrier()
+        seq_results = {r[0]: r for r in wl.results}
+        wl.results.clear()
+        ctx.barrier()
         t2 = time.time()
         run_steps(args.warmup, args.warmup + args.steps, depth=2)
-        barrier()
+        ctx.barrier()
         overlap_elapsed = time.time() - t2
-        same = all(np.array_equal(r[2], seq_results[r[0]][2]) and np.array_equal(r[6], seq_results[r[0]][6])
-                   for r in results)
+        same = all(wl.same_results(r, seq_results[r[0]]) for r in wl.results)
         overlap = (overlap_elapsed, same)
-        results[:] = [seq_results[b] for b in sorted(seq_results)]
-        log("two batches in flight: %d steps in %.3fs, identical poses: %s" % (args.steps, overlap_elapsed, same))
-    if dist is not None:
-        vals = [elapsed, overlap[0] if overlap else 0.0]
-        tmax = torch.tensor(vals, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0].item())
-        if overlap:
-            overlap = (float(tmax[1].item()), overlap[1])
+        wl.results[:] = [seq_results[b] for b in sorted(seq_results)]
+        ctx.log("two batches in flight: %d steps in %.3fs, identical results: %s" % (args.steps, overlap_elapsed, same))
+    # contract: the MAX over ranks of the barrier-to-barrier time; per-rank own times show the balance
+    elapsed, ov = ctx.reduce_max([elapsed, overlap[0] if overlap else 0.0])
+    if overlap:
+        overlap = (ov, overlap[1])
+    own = ctx.gather_floats([own_elapsed])[:, 0]
 
-    # ---- accuracy of the timed queries (outside the timed region) ---------------------------------------
-    t_l, r_l, hits, iters_all, nprob = [], [], 0, [], 0
-    for b, top, Tb, Tr, cdb, ok, iters, n_problems in results:
-        for i in range(BATCH):
-            qi = b * BATCH + i
-            t, r = harness.eval_pose(Tb[i], q_T[qi], np.eye(4), int(sym[top[i]]))
-            t_l.append(t)
-            r_l.append(r)
-            hits += int(top[i] == q_cad[qi])
-        iters_all.append(iters)
-        nprob += n_problems
-    agg = harness.aggregate(r_l, t_l)
-    iters_all = np.concatenate(iters_all)
-
-    if rank == 0:
-        dom = max(("conv", "ransac_eval", "ransac_pre", "knn", "chamfer"), key=lambda k: fam[k]["ms"])
-        d = fam[dom]
-        peak = {"knn": F64_PEAK_TFLOPS, "chamfer": F64_PEAK_TFLOPS, "ransac_pre": F16_PEAK_TFLOPS}.get(
-            dom, F32_PEAK_TFLOPS)
-        achieved = (d["flop"] / max(d["launches"], 1)) / (max(d["ms"], 1e-9) / max(d["launches"], 1) * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_count",
-                                                  "ransac_pre": "k_ransac_prefilter",
-                                                  "knn": "k_knn_feat", "chamfer": "k_chamfer"}[dom],
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": None, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
-                    "launches": d["launches"],
-                    "flop_per_launch": d["flop"] / max(d["launches"], 1),
-                    "concurrent": True,
-                    "note": ("k_ransac_prefilter: 64 FLOP per (hypothesis, pair) = the 32 f16 multiply-adds of "
-                             "the a_hi (b_hi + b_lo) residual expansion, against the dense f16 MFMA peak (the "
-                             "kernel's longer pipe is the VALU: one sign extraction per result); conv / "
-                             "k_ransac_count are priced against the f32 matrix peak (157.3 TF), kNN / Chamfer "
-                             "against the f64 matrix peak; see DESIGN.md")}
-        if solo and dom == "ransac_pre" and solo["launches"]:
-            a_solo = solo["flop"] / (solo["ms"] * 1e-3) / 1e12
-            roofline["solo"] = {"achieved": a_solo, "frac": a_solo / peak,
-                                "avg_launch_ms": solo["ms"] / solo["launches"], "launches": solo["launches"],
-                                "note": "same kernel and inputs with CS_RANSAC_OVERLAP=0 CORSAIR_SPLIT_RANSAC=0 "
-                                        "(nothing else on the GPU while it runs), extra untimed pass"}
-        # HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run of this same
-        # command (FETCH_SIZE / WRITE_SIZE passes; summary committed under profiles/)
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("kernel") == roofline["kernel"]:
-                roofline["traffic"] = tj["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = tj["source"]
-        total_q = args.steps * BATCH * world
+    cfg = wl.config(args.steps)   # every rank (accuracy bookkeeping of its own queries)
+    if ctx.rank == 0:
+        total_units = args.steps * wl.units_per_step * ctx.world
+        cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": depth})
         out = {
-            "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD chair",
-            "value": total_q / elapsed,
+            "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD %s"
+                      % ("chair" if args.workload == "stress" else args.workload),
+            "value": total_units / elapsed,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": ctx.world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -303,81 +674,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: single-MI355X Scan2CAD chair eval shape (C=%d catalog, "
-                                   "32 queries/step, 10k pts @ voxel 0.03, ResUNetBN2C+embedding random init, "
-                                   "top-1 retrieval, sym_pose RANSAC 100000x10)" % C,
-                       "queries_per_step": BATCH, "catalog": C, "catalog_embed_s": catalog_embed_s,
-                       "parallelism": "dp%d" % world, "batches_in_flight": depth,
-                       "ransac_problems_per_query": nprob / (args.steps * BATCH),
-                       "ransac_mean_iters": float(iters_all.mean()),
-                       "top1_hit_rate": hits / (args.steps * BATCH),
-                       "rre_mean_deg": agg["rre_mean_deg"], "rre_15": agg["rre_15"]},
-            "roofline": roofline,
+            "config": cfg,
+            "roofline": roofline_of(fam, solo, args),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         }
-        import ctypes
-        st = (ctypes.c_uint64 * 5)()
-        _lib.load().cs_ransac_prefilter_stats(st, 0)
-        out["ransac_prefilter"] = {"survivors": int(st[3]), "hypotheses": int(st[4]),
-                                   "note": "hypotheses whose f16 upper bound reached the best count and were "
-                                           "recounted exactly / all hypotheses evaluated (whole run incl. warmup)"}
+        if args.workload == "stress":
+            out["metric"] = "stress queries/sec (batch-64 forward + top-10 share), configs[4]"
+            out["kernel_tflops"] = {k: round(fam[k]["flop"] / max(fam[k]["ms"], 1e-9) / 1e9, 2)
+                                    for k in ("conv", "topk")}
+            out["est_full_job_s"] = 100000.0 * ctx.world / out["value"]  # 100k clouds + 10^6 x 10^6 top-10
+        if ctx.world > 1:
+            out["dist"] = {"backend": "rccl" if ctx.backend == "nccl" else ctx.backend,
+                           "devices_visible": ctx.n_devices,
+                           "rank_elapsed_s": [round(float(v), 4) for v in own],
+                           "rank_time_max_over_min": float(own.max() / max(own.min(), 1e-9))}
+        wl.extras(out)
         if overlap:
             out["two_batches_in_flight"] = {
-                "value": total_q / overlap[0], "unit": "queries/s", "ms_per_step": overlap[0] / args.steps * 1e3,
-                "identical_poses": bool(overlap[1]),
+                "value": total_units / overlap[0], "unit": "queries/s", "ms_per_step": overlap[0] / args.steps * 1e3,
+                "identical_results": bool(overlap[1]),
                 "note": "same K batches, two host threads x two HIP streams; not the contract number"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cfg, sd, emb, catalog, sym, q_clouds, q_ids)
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def cpu_baseline(args, cfg, sd, emb, catalog, sym, q_clouds, q_ids):
-    """The CPU oracle (kind "port": the build's restatement of the reference CPU path, OpenMP over
-    independent rows / registrations) timed on a bounded sample of the same workload: the first
-    `cpu_sample` queries of the first timed step -- embed, retrieve (against the same catalog
-    descriptors) and register against the top-1 CAD."""
-    from corsair_amd import registration as R
-    from oracle import native, post, resunet as oref, sparse as osp
-
-    native.load()
-    n = args.cpu_sample
-    first = args.warmup * BATCH
-    clouds = q_clouds[first:first + n]
-    cat_desc = catalog.desc.cpu().numpy()
-    cat_F = catalog.F.cpu().numpy()
-    cat_X = catalog.origin.cpu().numpy()
-    off = catalog.offsets
-    t0 = time.time()
-    grids, origins = [], []
-    for pc in clouds:
-        xyz, grid, _ = osp.quantize_cloud(pc, cfg.voxel_size)
-        grids.append(grid)
-        origins.append(xyz)
-    coords = osp.sparse_collate(grids)
-    feats = np.ones((coords.shape[0], 1), np.float32)
-    out, feat8, maps = oref.resunet_forward(sd, coords, feats)
-    desc = oref.embedding_forward(emb, feat8, maps["c8"][:, 0], n)
-    t_embed = time.time() - t0
-    rank_, _ = post.retrieval_rank(desc, cat_desc)
-    top = rank_[:, 0]
-    t_ret = time.time() - t0 - t_embed
-    qoff = np.concatenate([[0], np.cumsum([len(g) for g in grids])])
-    for i in range(n):
-        F0, x0 = out[qoff[i]:qoff[i + 1]], origins[i]
-        c = int(top[i])
-        F1, x1 = cat_F[off[c]:off[c + 1]], cat_X[off[c]:off[c + 1]]
-        gq = first + i
-        a0 = R.draw_anchors(len(F0), 100, 2 * gq)
-        a1 = R.draw_anchors(len(F1), 100, 2 * gq + 1)
-        post.sym_pose(F0, x0, F1, x1, int(sym[c]), cfg.k_nn, cfg.max_corr, 0, a0, a1,
-                      cfg.ransac_max_iter, cfg.ransac_confidence, force_gate=True)
-    total = time.time() - t0
-    return {"value": n / total, "unit": "queries/s", "cores": native.num_threads(), "kind": "port",
-            "sample": "%d queries of the first timed step: oracle embed %.2fs + retrieve %.3fs + sym_pose %.2fs"
-                      % (n, t_embed, t_ret, total - t_embed - t_ret)}
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

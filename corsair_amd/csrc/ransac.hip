@@ -1492,7 +1492,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                          dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
                          res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
-      prof_add_units("ransac_pre", 64.0 * eval_pairs);
+      // SURVEY 8d unit: 30 FLOP per (hypothesis, pair) -- the work of the exact formulation the prefilter
+      // stands in for (the matrix pipe executes 64 FLOP per pair: bench.py reports both)
+      prof_add_units("ransac_pre", 30.0 * eval_pairs);
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
                          dim3(256), 0, s, d_probs, cnt_up_r, it0, b, bmax, res_cnt.p, cand_err.p, hlist.p,
                          d_nsurv);

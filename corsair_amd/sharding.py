@@ -2,8 +2,10 @@
 "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests).
 
 The reference is single-device.  The path shards by independent units:
-  * catalog embedding: CAD model c is embedded by rank c % world (interleaved, so the voxel-count
-    imbalance between models averages out);
+  * catalog embedding: balanced by VOXEL COUNT, not item count (N1 varies 1.6 k - 8 k per
+    model): every rank counts the voxels of an interleaved slice (cs_voxelize only), the counts are
+    all-gathered (C int64, the only other collective) and `balanced_shards` deals the models out
+    largest-first to the lightest rank.  `shard_ids` (plain interleave) is the count-free fallback;
   * queries: embedding, retrieval and registration of a query are independent of every other query.
 The only exchange is ONE all-gather of the embedded catalog after the catalog pass: the global
 descriptors (f32 [C/world, 256] per rank, needed by every query's top-k) and the per-voxel features
@@ -26,6 +28,50 @@ def shard_ids(n, rank, world):
 def global_order(n, world):
     """Permutation that maps the concatenation of all shards (rank-major) back to item order."""
     return np.argsort(np.concatenate([np.arange(r, n, world) for r in range(world)]), kind="stable")
+
+
+def balanced_shards(weights, world):
+    """Longest-processing-time-first partition of items with the given weights (voxel counts) over
+    `world` ranks: items in order of decreasing weight (ties: smaller id) go to the rank with the
+    smallest load so far (ties: lowest rank).  Deterministic, identical on every rank.  Returns a list
+    of `world` ascending id lists.  The maximum load is within one item of the mean."""
+    w = np.asarray(weights, dtype=np.int64)
+    order = np.lexsort((np.arange(len(w)), -w))
+    load = np.zeros(world, dtype=np.int64)
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        shards[r].append(int(i))
+        load[r] += int(w[i])
+    return [sorted(s) for s in shards]
+
+
+def shard_order(shards):
+    """Permutation that maps the rank-major concatenation of `shards` back to item order."""
+    flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in shards]) if shards else np.zeros(0, np.int64)
+    return np.argsort(flat, kind="stable")
+
+
+def imbalance(weights, shards):
+    """max / mean load of a partition (1.0 = perfect)."""
+    w = np.asarray(weights, dtype=np.float64)
+    loads = np.asarray([w[s].sum() if len(s) else 0.0 for s in shards])
+    return float(loads.max() / max(loads.mean(), 1e-30))
+
+
+def all_gather_counts(dist, local_ids, local_counts, n_items, world):
+    """Voxel counts of all `n_items` items from the per-rank (ids, counts) slices: one all-gather of an
+    int64 [n_items] vector in which a rank fills only its own entries (the rest are zero)."""
+    v = torch.zeros(n_items, dtype=torch.int64)
+    if len(local_ids):
+        v[torch.as_tensor(list(local_ids), dtype=torch.int64)] = torch.as_tensor(list(local_counts), dtype=torch.int64)
+    if world == 1 or dist is None:
+        return v.numpy()
+    if dist.get_backend() == "nccl":
+        v = v.cuda()
+    out = [torch.empty_like(v) for _ in range(world)]
+    dist.all_gather(out, v)
+    return torch.stack(out).sum(0).cpu().numpy()
 
 
 def _stage_device(dist, t):
@@ -67,9 +113,11 @@ def all_gather_embedded(dist, eset, world):
     return sets
 
 
-def gather_catalog(dist, local_set, n_items, world):
-    """Full catalog (item order) from the per-rank shards."""
+def gather_catalog(dist, local_set, n_items, world, shards=None):
+    """Full catalog (item order) from the per-rank shards.  `shards` = the id lists the ranks embedded
+    (balanced_shards); default: the interleaved assignment of shard_ids."""
     if world == 1 or dist is None:
         return local_set
-    shards = all_gather_embedded(dist, local_set, world)
-    return concat_sets(shards).gather(global_order(n_items, world))
+    sets = all_gather_embedded(dist, local_set, world)
+    order = global_order(n_items, world) if shards is None else shard_order(shards)
+    return concat_sets(sets).gather(order)
