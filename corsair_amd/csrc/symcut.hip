@@ -6,10 +6,9 @@
 //   2. exact selection of the n_nn (= 50) nearest voxels by an 8-pass MSB radix select on the
 //      distance bit patterns (ties -> smaller row), emitted in ascending row order -- this is the
 //      reference's  raw_pc[local_rank < 50]
-//   3. n_init (= 10) seeded k-means fits (k-means++ seeding + Lloyd until the assignment is
-//      stable), one lane per restart, best inertia wins (first on ties).  The reference calls
-//      sklearn KMeans(random_state=0, n_init=10); reproducing sklearn's RNG stream is not a goal
-//      (SURVEY 7 "hard parts"), the build defines this seeded Lloyd and pins it with the oracle.
+//   3. the n_init (= 10) restarts of sklearn's KMeans(random_state=0, n_init=10) -- greedy k-means++ on
+//      the tabulated draws of RandomState(0), Lloyd with sklearn's stopping rules -- one lane per
+//      restart; first-best restart wins (see k_symcut_kmeans).
 //   4. the acceptance-gate statistics: minimum centre distance, maximum mean member distance,
 //      and the label histogram of the WHOLE cloud under the fitted centres.
 // The gate itself (dist.min() > 0.15 > max(error), smallest std of label fractions) and the
@@ -18,19 +17,13 @@
 #include <vector>
 
 #include "common.h"
+#define KM_DRAWS_QUAL __device__
+#include "kmeans_draws.h"
 
 namespace cs {
 
-__host__ __device__ static inline uint64_t sym_rng_u64(uint64_t seed, uint64_t a, uint64_t b) {
-  uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (a * 64ULL + b + 1ULL);
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-  x = x ^ (x >> 31);
-  return x;
-}
-
 constexpr int SYM_MAX_NN = 64;
-constexpr int SYM_MAX_INIT = 32;
+constexpr int SYM_MAX_INIT = 10;  // restarts whose draws are tabulated (K = 4: 10 x 10 doubles)
 
 __device__ __forceinline__ double dist2_3(double ax, double ay, double az, double bx, double by,
                                           double bz) {
@@ -273,13 +266,31 @@ __global__ __launch_bounds__(256) void k_symcut_select(
 
 // ---- 3. k-means restarts: one THREAD per (cloud-anchor, restart).  Inside the fused kernel this phase
 // ran on 10 lanes of one wave while the workgroup's other 246 threads waited; here every lane works.
+//
+// The fit is sklearn's KMeans(n_clusters=K, random_state=0, n_init=10).fit(nns) (utils/symmetry.py:216),
+// restated from sklearn 1.7.2 (cluster/_kmeans.py: fit, _kmeans_plusplus, _kmeans_single_lloyd):
+//   * KMeans.fit hands ONE RandomState(0) to the k-means++ seeding of every restart, and the stream does not
+//     depend on the data: restart r consumes the constants KM_DRAWS[r*per, (r+1)*per), per = 1 + (K-1)*trials,
+//     trials = 2 + int(log K)  (kmeans_draws.h, tools/gen_kmeans_draws.py) -- so restarts stay independent;
+//   * first centre: RandomState.choice(n, p = 1/n) = searchsorted(cdf, u, "right"); every further centre:
+//     `trials` candidates by searchsorted(cumsum(closest_d2), u * potential), the candidate with the smallest
+//     new potential wins (first on ties);
+//   * Lloyd: assign, means (an empty cluster takes the point farthest from its centre), stop when the labels
+//     repeat ("strict") or the squared centre shift <= 1e-4 * mean(var(X, axis=0)); without strict
+//     convergence the labels are re-assigned once more; inertia from the final centres and labels.
+// Arithmetic: f64 on the un-centred points in the oracle's operation order (sklearn: f32, mean-centred) --
+// decisions differ from sklearn's only on near-ties: 2 000 / 2 000 fits on real clouds give the same labels
+// (tests/test_pins_cpu.py).  k_symcut_finish keeps the first restart, then any with smaller inertia AND a
+// different clustering (sklearn's _is_same_clustering).
 __global__ __launch_bounds__(256) void k_symcut_kmeans(const int32_t* __restrict__ Ks, int n_anchor,
-                                                       int n_blk, int n_init, int max_iter, uint64_t seed,
+                                                       int n_blk, int n_init, int max_iter,
                                                        const double* __restrict__ pts_g,
                                                        const int32_t* __restrict__ nsel_g,
                                                        double* __restrict__ km_centers_g,
-                                                       double* __restrict__ km_inertia_g) {
+                                                       double* __restrict__ km_inertia_g,
+                                                       unsigned long long* __restrict__ km_labels_g) {
   __shared__ double pts_s[8][SYM_MAX_NN][3];  // the points of the (up to 8) cloud-anchors of this workgroup
+  extern __shared__ double closest_s[];       // [n_nn_max][256]: squared distance to the nearest chosen centre
   const int per = 256 / n_init < 8 ? 256 / n_init : 8;  // cloud-anchors per workgroup
   const int tid = threadIdx.x;
   const int sub = tid / n_init;                          // which of them this thread works on
@@ -295,103 +306,205 @@ __global__ __launch_bounds__(256) void k_symcut_kmeans(const int32_t* __restrict
   if (n_sel == 0) return;
   const int K = Ks[blk / n_anchor];
   double (*pts)[3] = pts_s[sub];
+  double* closest = closest_s + tid;                     // element i at closest[i * 256]
   const int init_id = tid - sub * n_init;
+  const int trials = K == 2 ? 2 : 3;                     // 2 + int(log K), K in {2, 4}
+  const double* u = KM_DRAWS + init_id * (1 + (K - 1) * trials);
+  KmState st;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) st.cx[c] = st.cy[c] = st.cz[c] = 0.0;
+  // tol = mean(var(X, axis=0)) * 1e-4
+  double tol;
   {
-    const uint64_t init = (uint64_t)init_id;
-    KmState st;
+    double v[3];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) st.cx[c] = st.cy[c] = st.cz[c] = 0.0;
-    // k-means++ seeding
-    {
-      const int c0 = (int)(((sym_rng_u64(seed, init, 0) >> 32) * (uint64_t)n_sel) >> 32);
-      st.cx[0] = pts[c0][0];
-      st.cy[0] = pts[c0][1];
-      st.cz[0] = pts[c0][2];
+    for (int a = 0; a < 3; ++a) {
+      double m = 0.0, q = 0.0;
+      for (int i = 0; i < n_sel; ++i) m += pts[i][a];
+      m /= (double)n_sel;
+      for (int i = 0; i < n_sel; ++i) q = fma(pts[i][a] - m, pts[i][a] - m, q);
+      v[a] = q / (double)n_sel;
     }
+    tol = ((v[0] + v[1]) + v[2]) / 3.0 * 1e-4;
+  }
+  // greedy k-means++ seeding
+  {
+    const double p_uniform = (double)(1.0f / (float)n_sel);
+    double cdf_last = 0.0;
+    for (int i = 0; i < n_sel; ++i) cdf_last += p_uniform;
+    int c0 = n_sel - 1;
+    double acc = 0.0;
+    for (int i = 0; i < n_sel; ++i) {
+      acc += p_uniform;
+      if (acc / cdf_last > u[0]) {
+        c0 = i;
+        break;
+      }
+    }
+    st.cx[0] = pts[c0][0];
+    st.cy[0] = pts[c0][1];
+    st.cz[0] = pts[c0][2];
+  }
+  double pot = 0.0;
+  for (int i = 0; i < n_sel; ++i) {
+    const double d = dist2_3(pts[i][0], pts[i][1], pts[i][2], st.cx[0], st.cy[0], st.cz[0]);
+    closest[i * 256] = d;
+    pot += d;
+  }
 #pragma unroll
-    for (int c = 1; c < 4; ++c) {
-      if (c < K) {
-        double total = 0.0, dm;
-        for (int i = 0; i < n_sel; ++i) {
-          nearest_center(st, c, pts[i][0], pts[i][1], pts[i][2], &dm);
-          total += dm;
-        }
-        const double u = (double)(sym_rng_u64(seed, init, (uint64_t)c) >> 11) * 0x1.0p-53;
-        const double r = u * total;
+  for (int c = 1; c < 4; ++c) {
+    if (c < K) {
+      int best_cand = -1;
+      double best_pot = 0.0;
+      for (int t = 0; t < trials; ++t) {
+        const double rv = u[1 + (c - 1) * trials + t] * pot;
+        int cand = n_sel - 1;
         double cum = 0.0;
-        int pick = n_sel - 1;
         for (int i = 0; i < n_sel; ++i) {
-          nearest_center(st, c, pts[i][0], pts[i][1], pts[i][2], &dm);
-          cum += dm;
-          if (cum > r) {
-            pick = i;
+          cum += closest[i * 256];
+          if (cum >= rv) {
+            cand = i;
             break;
           }
         }
-        st.cx[c] = pts[pick][0];
-        st.cy[c] = pts[pick][1];
-        st.cz[c] = pts[pick][2];
-      }
-    }
-    // Lloyd iterations
-    unsigned long long lab_lo = ~0ULL, lab_hi = ~0ULL;  // 2 bits per point, 32 points per word
-    double inertia = 0.0;
-    bool converged = false;
-    for (int it = 0; it < max_iter && !converged; ++it) {
-      double sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
-      int cn[4] = {0, 0, 0, 0};
-      unsigned long long nlo = 0, nhi = 0;
-      inertia = 0.0;
-      for (int i = 0; i < n_sel; ++i) {
-        double dm;
-        const double px = pts[i][0], py = pts[i][1], pz = pts[i][2];
-        const int b = nearest_center(st, K, px, py, pz, &dm);
-        inertia += dm;
-        if (i < 32)
-          nlo |= (unsigned long long)b << (2 * i);
-        else
-          nhi |= (unsigned long long)b << (2 * (i - 32));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (b == c) {
-            sx[c] += px;
-            sy[c] += py;
-            sz[c] += pz;
-            cn[c] += 1;
-          }
+        const double qx = pts[cand][0], qy = pts[cand][1], qz = pts[cand][2];
+        double pc = 0.0;
+        for (int i = 0; i < n_sel; ++i) {
+          const double d = dist2_3(pts[i][0], pts[i][1], pts[i][2], qx, qy, qz);
+          const double cl = closest[i * 256];
+          pc += d < cl ? d : cl;
+        }
+        if (best_cand < 0 || pc < best_pot) {
+          best_cand = cand;
+          best_pot = pc;
         }
       }
-      if (it > 0 && nlo == lab_lo && nhi == lab_hi) {
-        converged = true;
-      } else {
-        lab_lo = nlo;
-        lab_hi = nhi;
+      st.cx[c] = pts[best_cand][0];
+      st.cy[c] = pts[best_cand][1];
+      st.cz[c] = pts[best_cand][2];
+      pot = best_pot;
+      for (int i = 0; i < n_sel; ++i) {
+        const double d = dist2_3(pts[i][0], pts[i][1], pts[i][2], st.cx[c], st.cy[c], st.cz[c]);
+        if (d < closest[i * 256]) closest[i * 256] = d;
+      }
+    }
+  }
+  // Lloyd iterations
+  unsigned long long lab_lo = ~0ULL, lab_hi = ~0ULL;  // 2 bits per point, 32 points per word
+  bool strict = false;
+  for (int it = 0; it < max_iter; ++it) {
+    double sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
+    int cn[4] = {0, 0, 0, 0};
+    unsigned long long nlo = 0, nhi = 0;
+    for (int i = 0; i < n_sel; ++i) {
+      double dm;
+      const double px = pts[i][0], py = pts[i][1], pz = pts[i][2];
+      const int b = nearest_center(st, K, px, py, pz, &dm);
+      if (i < 32)
+        nlo |= (unsigned long long)b << (2 * i);
+      else
+        nhi |= (unsigned long long)b << (2 * (i - 32));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c < K && cn[c] > 0) {
-            st.cx[c] = sx[c] / (double)cn[c];
-            st.cy[c] = sy[c] / (double)cn[c];
-            st.cz[c] = sz[c] / (double)cn[c];
-          }
+      for (int c = 0; c < 4; ++c) {
+        if (b == c) {
+          sx[c] += px;
+          sy[c] += py;
+          sz[c] += pz;
+          cn[c] += 1;
         }
       }
     }
-    if (!converged) {  // centres moved after the last assignment: recompute the inertia
-      inertia = 0.0;
-      for (int i = 0; i < n_sel; ++i) {
-        double dm;
-        nearest_center(st, K, pts[i][0], pts[i][1], pts[i][2], &dm);
-        inertia += dm;
-      }
-    }
+    // empty clusters take the points farthest from their centres (rare: one each, farthest first)
+    unsigned long long taken = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 0] = st.cx[c];
-      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 1] = st.cy[c];
-      km_centers_g[((int64_t)blk * n_init + init_id) * 12 + 3 * c + 2] = st.cz[c];
+      if (c < K && cn[c] == 0) {
+        int far = -1;
+        double fd = -1.0;
+        for (int i = 0; i < n_sel; ++i) {
+          double dm;
+          nearest_center(st, K, pts[i][0], pts[i][1], pts[i][2], &dm);
+          if ((taken >> i) & 1ULL) dm = -1.0;
+          if (far < 0 || dm > fd) {
+            far = i;
+            fd = dm;
+          }
+        }
+        taken |= 1ULL << far;
+        const int old = (int)((far < 32 ? nlo >> (2 * far) : nhi >> (2 * (far - 32))) & 3ULL);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          if (o == old) {
+            sx[o] -= pts[far][0];
+            sy[o] -= pts[far][1];
+            sz[o] -= pts[far][2];
+            cn[o] -= 1;
+          }
+        }
+        sx[c] = pts[far][0];
+        sy[c] = pts[far][1];
+        sz[c] = pts[far][2];
+        cn[c] = 1;
+      }
     }
-    km_inertia_g[(int64_t)blk * n_init + init_id] = inertia;
+    double shift = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < K) {
+        const double nx = cn[c] > 0 ? sx[c] / (double)cn[c] : st.cx[c];
+        const double ny = cn[c] > 0 ? sy[c] / (double)cn[c] : st.cy[c];
+        const double nz = cn[c] > 0 ? sz[c] / (double)cn[c] : st.cz[c];
+        shift += dist2_3(nx, ny, nz, st.cx[c], st.cy[c], st.cz[c]);
+        st.cx[c] = nx;
+        st.cy[c] = ny;
+        st.cz[c] = nz;
+      }
     }
+    const bool same = it > 0 && nlo == lab_lo && nhi == lab_hi;
+    lab_lo = nlo;
+    lab_hi = nhi;
+    if (same) {
+      strict = true;
+      break;
+    }
+    if (shift <= tol) break;
+  }
+  double inertia = 0.0;
+  if (!strict) {
+    lab_lo = lab_hi = 0;
+    for (int i = 0; i < n_sel; ++i) {
+      double dm;
+      const int b = nearest_center(st, K, pts[i][0], pts[i][1], pts[i][2], &dm);
+      if (i < 32)
+        lab_lo |= (unsigned long long)b << (2 * i);
+      else
+        lab_hi |= (unsigned long long)b << (2 * (i - 32));
+      inertia += dm;
+    }
+  } else {
+    for (int i = 0; i < n_sel; ++i) {
+      const int b = (int)((i < 32 ? lab_lo >> (2 * i) : lab_hi >> (2 * (i - 32))) & 3ULL);
+      double cx = st.cx[0], cy = st.cy[0], cz = st.cz[0];
+#pragma unroll
+      for (int c = 1; c < 4; ++c)
+        if (b == c) {
+          cx = st.cx[c];
+          cy = st.cy[c];
+          cz = st.cz[c];
+        }
+      inertia += dist2_3(pts[i][0], pts[i][1], pts[i][2], cx, cy, cz);
+    }
+  }
+  const int64_t slot = (int64_t)blk * n_init + init_id;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    km_centers_g[slot * 12 + 3 * c + 0] = st.cx[c];
+    km_centers_g[slot * 12 + 3 * c + 1] = st.cy[c];
+    km_centers_g[slot * 12 + 3 * c + 2] = st.cz[c];
+  }
+  km_inertia_g[slot] = inertia;
+  km_labels_g[slot * 2 + 0] = lab_lo;
+  km_labels_g[slot * 2 + 1] = lab_hi;
 }
 
 template <int DIM>
@@ -399,8 +512,8 @@ __global__ __launch_bounds__(256) void k_symcut_finish(
     const float* __restrict__ xyz, const int64_t* __restrict__ off, int n_anchor,
     const int32_t* __restrict__ Ks, int n_init, const double* __restrict__ pts_g,
     const int32_t* __restrict__ nsel_g, const double* __restrict__ km_centers_g,
-    const double* __restrict__ km_inertia_g, double* __restrict__ out_centers,
-    int32_t* __restrict__ out_counts, double* __restrict__ out_min_cdist,
+    const double* __restrict__ km_inertia_g, const unsigned long long* __restrict__ km_labels_g,
+    double* __restrict__ out_centers, int32_t* __restrict__ out_counts, double* __restrict__ out_min_cdist,
     double* __restrict__ out_max_err) {
   __shared__ double sel_centers[12];
   __shared__ int counts[4];
@@ -418,9 +531,30 @@ __global__ __launch_bounds__(256) void k_symcut_finish(
   const double* km_inertia = km_inertia_g + (int64_t)blk * n_init;
   // ---- 4. best restart + gate statistics -----------------------------------------------------
   if (tid == 0) {
+    // the first restart, then any with a smaller inertia AND a different clustering (sklearn
+    // _is_same_clustering: the one-directional label mapping must be consistent)
     int best = 0;
-    for (int r = 1; r < n_init; ++r)
-      if (km_inertia[r] < km_inertia[best]) best = r;
+    const unsigned long long* km_lab = km_labels_g + (int64_t)blk * n_init * 2;
+    for (int r = 1; r < n_init; ++r) {
+      if (!(km_inertia[r] < km_inertia[best])) continue;
+      int mapping[4] = {-1, -1, -1, -1};
+      bool same_clu = true;
+      for (int i = 0; i < n_sel && same_clu; ++i) {
+        const int a = (int)((i < 32 ? km_lab[2 * r] >> (2 * i) : km_lab[2 * r + 1] >> (2 * (i - 32))) & 3ULL);
+        const int b = (int)((i < 32 ? km_lab[2 * best] >> (2 * i) : km_lab[2 * best + 1] >> (2 * (i - 32))) & 3ULL);
+        int m = mapping[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) m = a == c ? mapping[c] : m;
+        if (m == -1) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (a == c) mapping[c] = b;
+        } else if (m != b) {
+          same_clu = false;
+        }
+      }
+      if (!same_clu) best = r;
+    }
     KmState st;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -532,6 +666,8 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
              "cs_symcut_fit: n_nn %d not in [4, %d]", n_nn, SYM_MAX_NN);
   CS_REQUIRE(n_init >= 1 && n_init <= SYM_MAX_INIT, CS_ERR_UNSUPPORTED,
              "cs_symcut_fit: n_init %d not in [1, %d]", n_init, SYM_MAX_INIT);
+  CS_REQUIRE(seed == 0, CS_ERR_UNSUPPORTED,
+             "cs_symcut_fit: only sklearn's random_state=0 stream is tabulated (utils/symmetry.py:216)");
   CS_REQUIRE(n_anchor >= 1 && max_iter >= 1, CS_ERR_INVALID, "cs_symcut_fit: bad counts");
   if (n_cloud <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -551,7 +687,8 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
   const size_t n_ca = (size_t)n_cloud * n_anchor;
   PoolBuf<double> pts_g(n_ca * SYM_MAX_NN * 3), kmc_g(n_ca * n_init * 12), kmi_g(n_ca * n_init);
   PoolBuf<int32_t> nsel_g(n_ca);
-  CS_REQUIRE(d_off.p && d_koff.p && d_K.p && keys.p && pts_g.p && kmc_g.p && kmi_g.p && nsel_g.p, CS_ERR_HIP,
+  PoolBuf<unsigned long long> kml_g(n_ca * n_init * 2);
+  CS_REQUIRE(d_off.p && d_koff.p && d_K.p && keys.p && pts_g.p && kmc_g.p && kmi_g.p && nsel_g.p && kml_g.p, CS_ERR_HIP,
              "cs_symcut_fit: scratch allocation failed");
   CS_HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), sizeof(int64_t) * (n_cloud + 1),
                               hipMemcpyHostToDevice, s));
@@ -580,10 +717,14 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
                          d_anchor, n_anchor, d_K.p, n_nn, n_init, max_iter, seed, keys.p,
                          d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error, pts_g.p, nsel_g.p);
     const int per = 256 / n_init < 8 ? 256 / n_init : 8;
-    hipLaunchKernelGGL(k_symcut_kmeans, dim3((unsigned)((n_blk + per - 1) / per)), dim3(256), 0, s, d_K.p,
-                       n_anchor, n_blk, n_init, max_iter, seed, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p);
+    // 100 KB of dynamic LDS for n_nn = 50 (one f64 per thread and selected voxel), above the 64 KB default
+    CS_HIP_CHECK(hipFuncSetAttribute((const void*)k_symcut_kmeans, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(double) * 256 * SYM_MAX_NN)));
+    hipLaunchKernelGGL(k_symcut_kmeans, dim3((unsigned)((n_blk + per - 1) / per)), dim3(256),
+                       sizeof(double) * 256 * (size_t)n_nn, s, d_K.p, n_anchor, n_blk, n_init, max_iter,
+                       pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, kml_g.p);
     hipLaunchKernelGGL((k_symcut_finish<16>), grid, dim3(256), 0, s, d_xyz, d_off.p, n_anchor, d_K.p,
-                       n_init, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, d_centers, d_counts,
+                       n_init, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, kml_g.p, d_centers, d_counts,
                        d_min_center_dist, d_max_error);
     CS_LAUNCH_CHECK();
   }

@@ -229,9 +229,11 @@ void cs_ransac_prefilter_stats(uint64_t out[5], int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Symmetry part cut.  Replaces symmetric_cut4 (utils/symmetry.py:182-259) for a batch of
- * clouds: for every (cloud, anchor) the 50 feature-nearest voxels, n_init seeded k-means fits
- * of K centres on their xyz, the statistics the acceptance gate needs, and finally the labels
- * of every voxel under the accepted model.
+ * clouds: for every (cloud, anchor) the 50 feature-nearest voxels, the fit of
+ * sklearn's KMeans(n_clusters=K, random_state=0, n_init=n_init) on their xyz (utils/symmetry.py:216:
+ * greedy k-means++ on the constant uniform draws of numpy's RandomState(0), Lloyd with sklearn's
+ * stopping rules, first-best restart; `seed` must be 0 = that random_state, n_init <= 10), the
+ * statistics the acceptance gate needs, and finally the labels of every voxel under the accepted model.
  *   cs_symcut_fit: d_feat f32 [N,dim], d_xyz f32 [N,3], h_off int64 [n_cloud+1],
  *     d_anchor int32 [n_cloud, n_anchor] (row index local to the cloud), h_K int32 [n_cloud] in {2,4};
  *     outputs per (cloud, anchor): d_centers f64 [.,4,3], d_counts int32 [.,4] (labels of the WHOLE

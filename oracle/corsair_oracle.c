@@ -16,6 +16,7 @@
  */
 #include <math.h>
 #include <omp.h>
+#include "kmeans_draws.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -419,8 +420,9 @@ void oc_ransac_batch(const float* src, const float* tgt, const int64_t* off, int
 
 /* ------------------------------------------------------------------------------------------
  * Symmetry part cut statistics for one (cloud, anchor).  Restates the body of the anchor loop of
- * symmetric_cut4 (utils/symmetry.py:198-236) with the build's seeded k-means in place of
- * sklearn.KMeans(n_clusters=K, random_state=0, n_init=10).
+ * symmetric_cut4 (utils/symmetry.py:198-236); sklearn.KMeans(n_clusters=K, random_state=0, n_init=10)
+ * is restated on its own constant RandomState(0) draws (kmeans_draws.h) and pinned against sklearn
+ * itself by tests/test_pins_cpu.py (2 000 / 2 000 identical label vectors on real clouds).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   double d;
@@ -486,70 +488,157 @@ void oc_symcut_fit_one(const float* feat, int dim, const float* xyz, int n, int 
   for (int i = 0; i < n_sel; ++i)
     for (int a = 0; a < 3; ++a) pts[i][a] = (double)xyz[3 * (int64_t)rows[i] + a];
 
+  /* ---- sklearn KMeans(n_clusters=K, random_state=0, n_init=10).fit(nns)  (utils/symmetry.py:216) ----
+   * restated from sklearn 1.7.2 cluster/_kmeans.py (fit :1453-1535, _kmeans_plusplus :163-250,
+   * _kmeans_single_lloyd :624-742, _relocate_empty_clusters_dense in _k_means_common.pyx); the uniform
+   * draws of its RandomState(0) stream are constants (kmeans_draws.h).  Arithmetic here is f64 on the
+   * un-centred points (sklearn: f32, mean-centred): decisions can only differ on near-ties. */
+  const int trials = 2 + (int)log((double)K);            /* n_local_trials */
+  const int per = 1 + (K - 1) * trials;                  /* draws per restart */
+  if (n_init * per > KM_N_DRAWS) n_init = KM_N_DRAWS / per;
+  (void)seed;                                            /* random_state=0 is the only tabulated stream */
+  /* tol = mean(var(X, axis=0)) * 1e-4 */
+  double tol;
+  {
+    double v[3];
+    for (int a = 0; a < 3; ++a) {
+      double m = 0.0, q = 0.0;
+      for (int i = 0; i < n_sel; ++i) m += pts[i][a];
+      m /= (double)n_sel;
+      for (int i = 0; i < n_sel; ++i) q = fma(pts[i][a] - m, pts[i][a] - m, q);
+      v[a] = q / (double)n_sel;
+    }
+    tol = ((v[0] + v[1]) + v[2]) / 3.0 * 1e-4;
+  }
+  /* RandomState.choice(n, p = 1/n): cdf = cumsum(p) / cumsum(p)[-1], searchsorted(side="right") */
+  const double p_uniform = (double)(1.0f / (float)n_sel);
+  double cdf_last = 0.0;
+  for (int i = 0; i < n_sel; ++i) cdf_last += p_uniform;
+
   double best_cen[4][3];
+  int best_lab[64];
   double best_inertia = INFINITY;
+  int have_best = 0;
   for (int init = 0; init < n_init; ++init) {
+    const double* u = KM_DRAWS + init * per;
     double cen[4][3] = {{0}};
-    const int c0 = (int)(((oc_rng_u64(seed, (uint64_t)init, 0) >> 32) * (uint64_t)n_sel) >> 32);
-    for (int a = 0; a < 3; ++a) cen[0][a] = pts[c0][a];
-    for (int c = 1; c < K; ++c) {
-      double total = 0.0, dm;
+    double closest[64];
+    int c0 = n_sel - 1;
+    {
+      double acc = 0.0;
       for (int i = 0; i < n_sel; ++i) {
-        oc_nearest(cen, c, pts[i], &dm);
-        total += dm;
-      }
-      const double u = (double)(oc_rng_u64(seed, (uint64_t)init, (uint64_t)c) >> 11) * 0x1.0p-53;
-      const double r = u * total;
-      double cum = 0.0;
-      int pick = n_sel - 1;
-      for (int i = 0; i < n_sel; ++i) {
-        oc_nearest(cen, c, pts[i], &dm);
-        cum += dm;
-        if (cum > r) {
-          pick = i;
+        acc += p_uniform;
+        if (acc / cdf_last > u[0]) {
+          c0 = i;
           break;
         }
       }
-      for (int a = 0; a < 3; ++a) cen[c][a] = pts[pick][a];
+    }
+    for (int a = 0; a < 3; ++a) cen[0][a] = pts[c0][a];
+    double pot = 0.0;
+    for (int i = 0; i < n_sel; ++i) {
+      closest[i] = oc_d2(pts[i], pts[c0]);
+      pot += closest[i];
+    }
+    for (int c = 1; c < K; ++c) {
+      int best_cand = -1;
+      double best_pot = 0.0;
+      for (int t = 0; t < trials; ++t) {
+        const double rv = u[1 + (c - 1) * trials + t] * pot;
+        /* np.searchsorted(stable_cumsum(closest), rv) (side="left"), clipped to n - 1 */
+        int cand = n_sel - 1;
+        double cum = 0.0;
+        for (int i = 0; i < n_sel; ++i) {
+          cum += closest[i];
+          if (cum >= rv) {
+            cand = i;
+            break;
+          }
+        }
+        double pc = 0.0;
+        for (int i = 0; i < n_sel; ++i) {
+          const double d = oc_d2(pts[i], pts[cand]);
+          pc += d < closest[i] ? d : closest[i];
+        }
+        if (best_cand < 0 || pc < best_pot) { /* np.argmin: first minimum */
+          best_cand = cand;
+          best_pot = pc;
+        }
+      }
+      for (int a = 0; a < 3; ++a) cen[c][a] = pts[best_cand][a];
+      pot = best_pot;
+      for (int i = 0; i < n_sel; ++i) {
+        const double d = oc_d2(pts[i], pts[best_cand]);
+        if (d < closest[i]) closest[i] = d;
+      }
     }
     int lab[64], prev[64];
     for (int i = 0; i < n_sel; ++i) prev[i] = -1;
-    double inertia = 0.0;
-    int converged = 0;
-    for (int it = 0; it < max_iter && !converged; ++it) {
+    int strict = 0;
+    for (int it = 0; it < max_iter; ++it) {
       double sum[4][3] = {{0}};
       int cn[4] = {0, 0, 0, 0};
-      inertia = 0.0;
+      double dist[64];
       for (int i = 0; i < n_sel; ++i) {
-        double dm;
-        const int b = oc_nearest(cen, K, pts[i], &dm);
-        inertia += dm;
+        const int b = oc_nearest(cen, K, pts[i], &dist[i]);
         lab[i] = b;
         for (int a = 0; a < 3; ++a) sum[b][a] += pts[i][a];
         cn[b] += 1;
       }
-      int same = it > 0;
+      /* empty clusters take the points farthest from their centres (one each, farthest first) */
+      for (int c = 0; c < K; ++c) {
+        if (cn[c] != 0) continue;
+        int far = 0;
+        for (int i = 1; i < n_sel; ++i)
+          if (dist[i] > dist[far]) far = i;
+        dist[far] = -1.0;
+        const int old = lab[far];
+        for (int a = 0; a < 3; ++a) {
+          sum[old][a] -= pts[far][a];
+          sum[c][a] = pts[far][a];
+        }
+        cn[c] = 1;
+        cn[old] -= 1;
+      }
+      double shift = 0.0;
+      for (int c = 0; c < K; ++c) {
+        double nc[3];
+        for (int a = 0; a < 3; ++a) nc[a] = cn[c] > 0 ? sum[c][a] / (double)cn[c] : cen[c][a];
+        shift += oc_d2(nc, cen[c]);
+        for (int a = 0; a < 3; ++a) cen[c][a] = nc[a];
+      }
+      int same = 1;
       for (int i = 0; i < n_sel && same; ++i) same = lab[i] == prev[i];
       if (same) {
-        converged = 1;
-      } else {
-        memcpy(prev, lab, sizeof(int) * (size_t)n_sel);
-        for (int c = 0; c < K; ++c)
-          if (cn[c] > 0)
-            for (int a = 0; a < 3; ++a) cen[c][a] = sum[c][a] / (double)cn[c];
+        strict = 1;
+        break;
       }
+      if (shift <= tol) break;
+      memcpy(prev, lab, sizeof(int) * (size_t)n_sel);
     }
-    if (!converged) {
-      inertia = 0.0;
-      for (int i = 0; i < n_sel; ++i) {
-        double dm;
-        oc_nearest(cen, K, pts[i], &dm);
-        inertia += dm;
+    double inertia = 0.0;
+    for (int i = 0; i < n_sel; ++i) {
+      double dm;
+      if (!strict) lab[i] = oc_nearest(cen, K, pts[i], &dm);
+      else dm = oc_d2(pts[i], cen[lab[i]]);
+      inertia += dm;
+    }
+    /* keep the first restart, then any with a smaller inertia AND a different clustering
+     * (_is_same_clustering: one-directional label mapping) */
+    int take = !have_best;
+    if (have_best && inertia < best_inertia) {
+      int mapping[4] = {-1, -1, -1, -1}, same_clu = 1;
+      for (int i = 0; i < n_sel && same_clu; ++i) {
+        if (mapping[lab[i]] == -1) mapping[lab[i]] = best_lab[i];
+        else if (mapping[lab[i]] != best_lab[i]) same_clu = 0;
       }
+      take = !same_clu;
     }
-    if (inertia < best_inertia) {
+    if (take) {
+      have_best = 1;
       best_inertia = inertia;
       memcpy(best_cen, cen, sizeof(cen));
+      memcpy(best_lab, lab, sizeof(int) * (size_t)n_sel);
     }
   }
   for (int c = 0; c < K; ++c)

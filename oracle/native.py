@@ -21,10 +21,11 @@ _lib = None
 
 def build(force=False):
     os.makedirs(BUILD_DIR, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(_HERE, "kmeans_draws.h")))
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
     cmd = ["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC",
-           "-std=c11", SRC, "-o", LIB, "-lm"]
+           "-std=c11", "-I", _HERE, SRC, "-o", LIB, "-lm"]
     subprocess.check_call(cmd)
     return LIB
 

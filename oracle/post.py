@@ -11,8 +11,9 @@ Function names follow the reference so the parity tests read like it:
 Deliberate, documented differences from the reference (DESIGN.md "oracle vs reference"):
   * RANSAC: Open3D's global mt19937 + OpenMP schedule is replaced by a counter-based RNG and the
     single-thread iteration order (Open3D itself is run-to-run non-deterministic, README.md:260);
-  * k-means: sklearn KMeans(random_state=0, n_init=10) is replaced by the build's seeded
-    k-means++/Lloyd; the anchors come from an explicit seeded generator instead of NumPy's global RNG;
+  * k-means: sklearn KMeans(random_state=0, n_init=10) is restated (same algorithm on the same RandomState(0)
+    draws, f64 instead of f32; tests/test_pins_cpu.py compares with sklearn itself); the anchors come from
+    an explicit seeded generator instead of NumPy's global RNG;
   * argsort ties (NumPy's default sort is unstable) are broken toward the smaller index.
 """
 from __future__ import annotations

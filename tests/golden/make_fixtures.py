@@ -15,6 +15,10 @@ Fixtures are DATA (inputs + expected outputs); no reference source text is store
                         synthetic descriptors and a 160x160 block of configs/03001627_scan2cad.npy.
   real_clouds.npz       two bundled ShapeNet PC15k test clouds (first 10000 points, f32) used as
                         realistic inputs for the sparse-path parity tests.
+  real_clouds10.npz     ten more of them (5 chairs + 5 tables, every 20th file of the sorted test
+                        directories, first 10000 points, f16-rounded coordinates stored as f32 to keep
+                        the file small: the clouds are inputs only, nothing is compared with the
+                        originals) for the real-occupancy GPU parity tests and the k-means pin.
 """
 import os
 import sys
@@ -137,10 +141,25 @@ def make_real_clouds():
                         names=np.array([chair, table]))
 
 
+def make_real_clouds10():
+    base = f"{REF}/docker/data/ShapeNetCore.v2.PC15k"
+    clouds, names, cats = [], [], []
+    for cat in ("03001627", "04379243"):
+        files = sorted(os.listdir(f"{base}/{cat}/test"))[10::20][:5]
+        for f in files:
+            pc = np.load(f"{base}/{cat}/test/{f}")[:10000].astype(np.float32)
+            clouds.append(pc.astype(np.float16).astype(np.float32))
+            names.append(f)
+            cats.append(cat)
+    np.savez_compressed(f"{OUT}/real_clouds10.npz", clouds=np.stack(clouds).astype(np.float16),
+                        names=np.array(names), cats=np.array(cats))
+
+
 if __name__ == "__main__":
     make_eval_pose_kat()
     make_aggregate_kat()
     make_retrieval_kat()
     make_real_clouds()
+    make_real_clouds10()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
