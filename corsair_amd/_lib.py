@@ -56,7 +56,7 @@ def _declare(lib):
                                     POINTER(c_int32), c_int, vp, vp, vp]),
         "cs_hausdorff_1dir": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), POINTER(c_int32),
                                       POINTER(c_int32), c_int, vp, vp, vp]),
-        "cs_ransac_batch": (c_int, [vp, vp, POINTER(c_int64), c_int, c_float, c_int, c_int, c_double,
+        "cs_ransac_batch": (c_int, [vp, vp, POINTER(c_int64), c_int, c_double, c_int, c_int, c_double,
                                     c_uint64, vp, vp, vp, vp, vp]),
         "cs_ransac_prefilter_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_knn_shortlist_stats": (None, [POINTER(c_uint64), c_int]),

@@ -7,21 +7,23 @@
 // problem is reproducible anywhere.  Iterations are processed in growing chunks (256, 256, 512, ...,
 // 16 384); within a chunk
 //   k_ransac_hyp        one lane per hypothesis: sample ransac_n pairs (packed 32-B rows), closed-form
-//                       rigid fit (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f32
+//                       rigid fit (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f64
+//                       (Open3D keeps the Matrix4d; the f32 cast happens at the very end, where the
+//                       reference casts the result: utils/symmetry.py:274)
 //   k_ransac_prefilter  (from iteration 512 on) an UPPER bound of every hypothesis' inlier count on the
 //                       f16 matrix cores; hypotheses whose bound is below the carried best cannot
 //                       matter and get count 0.  ~0.02 % survive.  See the block comment above the
 //                       kernel and DESIGN.md ("RANSAC prefilter") for the bound.
-//   k_ransac_count      the exact count: a wave owns 32 hypotheses; the residual d = R s + t - q of a
-//                       32-correspondence x 32-hypothesis tile is TWO v_mfma_f32_32x32x2_f32 per
-//                       coordinate (K = [sx, sy | sz, 1] against [r0, r1 | r2, t]) whose accumulator
-//                       INPUT is -q read straight from LDS; the VALU does the squared norm, compare
-//                       and count.  f32 MFMA is an ordered fma chain, so the inlier test is
-//                       bit-identical to the scalar oracle:
-//                       d = fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))).
-//                       Used for all hypotheses of the first 512 iterations and (LIST) for long
-//                       survivor lists; k_ransac_count_few handles the usual handful of survivors
-//                       (canonical chain on the VALU, count and fixed-point error in one pass).
+//   k_ransac_count      the exact count in Open3D's arithmetic: the reference hands Open3D f64 points
+//                       (utils/eval_pose.py:83-86) and Eigen transforms and compares in double, so the
+//                       inlier test is evaluated in f64: a lane owns one hypothesis (R|t in 12 f64
+//                       registers), the pairs of a 256-row stage are converted to f64 once and read
+//                       from LDS as broadcasts; p = fma(r2,sz, fma(r1,sy, fma(r0,sx, t))), d = p - q,
+//                       |d|^2 = fma(dz,dz, fma(dy,dy, dx dx)) < max_corr^2 (the canonical chain, the
+//                       oracle's).  Used for all hypotheses of the first 512 iterations and (LIST) for
+//                       long survivor lists; k_ransac_count_few handles the usual handful of survivors
+//                       (same chain, count and fixed-point error in one pass).  These kernels see
+//                       ~0.1 % of the (hypothesis, pair) work; the f16 prefilter carries the rest.
 //   k_ransac_scan1      one wave per problem replays the chunk in iteration order (prefix max of the
 //                       inlier counts -> early-exit bound est_k -> stop position) and lists the
 //                       hypotheses that tie for the best count
@@ -58,7 +60,7 @@ struct RansacProb {
   // per-chunk scratch written by scan1, read by err / scan2
   int32_t n_cand;
   int32_t chunk_max;
-  float best_T[12];
+  double best_T[12];
 };
 
 // The kernels of a round's front half (hypotheses, f16 rows, prefilter) may run while the previous
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed,
                                                     const int32_t* __restrict__ xcd_prob, int slots,
-                                                    int tiles, float* __restrict__ hyp) {
+                                                    int tiles, double* __restrict__ hyp) {
   // 1-D grid dealt round-robin to the XCDs: XCD x samples only the problems xcd_prob[x][.], whose
   // correspondences then stay in that XCD's L2 (the sampling is a random gather of 24-B rows)
   const int xcd = blockIdx.x & 7;
@@ -284,49 +286,46 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
   R[2][0] = 2.0 * (qx * qz - qw * qy);
   R[2][1] = 2.0 * (qy * qz + qw * qx);
   R[2][2] = 1.0 - 2.0 * (qx * qx + qy * qy);
-  float* o = hyp + ((int64_t)p * 12) * bmax + h;
+  double* o = hyp + ((int64_t)p * 12) * bmax + h;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double t = ct_[a] - (R[a][0] * cs_[0] + R[a][1] * cs_[1] + R[a][2] * cs_[2]);
-    o[(int64_t)(4 * a + 0) * bmax] = (float)R[a][0];
-    o[(int64_t)(4 * a + 1) * bmax] = (float)R[a][1];
-    o[(int64_t)(4 * a + 2) * bmax] = (float)R[a][2];
-    o[(int64_t)(4 * a + 3) * bmax] = (float)t;
+    o[(int64_t)(4 * a + 0) * bmax] = R[a][0];
+    o[(int64_t)(4 * a + 1) * bmax] = R[a][1];
+    o[(int64_t)(4 * a + 2) * bmax] = R[a][2];
+    o[(int64_t)(4 * a + 3) * bmax] = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Inlier counting on the matrix pipe.
-// grid: x = (hypothesis tile of 128) * splits + split, y = problem; block = 4 waves x 32 hypotheses.
-// MFMA operand maps (v_mfma_f32_32x32x2_f32): lane l supplies A[row l&31][k = l>>5] and
-// B[k = l>>5][col l&31]; D[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31] in register r.
-// rows = correspondences, cols = hypotheses: a lane owns ONE hypothesis and, per tile, 16
-// correspondences.  The accumulator INPUT is loaded with -target straight from LDS, so the MFMA
-// chain delivers the residual d = R s + t - q itself and the VALU is left with 3 fma-class ops, one
-// compare and one add-with-carry per pair (the kernel is VALU-issue bound otherwise: a wave64 f32
-// VALU op occupies the SIMD for 4 cycles on gfx950, measured with SQ_ACTIVE_INST_VALU).
+// Exact inlier counts, f64 (Open3D evaluates Matrix4d * Vector4d and squaredNorm in double).
+// grid: x = (hypothesis tile of 256) * splits + split, y = problem; block = 256 lanes = 256 hypotheses.
+// A lane keeps its hypothesis in 12 f64 registers and walks the pair range of its split; pairs are
+// staged 256 at a time: each thread loads one pair (6 coalesced f32 loads from the SoA copy), converts
+// it to f64 once and stores it as one 48-B LDS row, which all lanes then read as broadcasts.
+// Canonical chain (oracle/corsair_oracle.c oc_ransac):
+//   p_c = fma(r_c2, sz, fma(r_c1, sy, fma(r_c0, sx, t_c))),  d_c = p_c - q_c,
+//   |d|^2 = fma(dz, dz, fma(dy, dy, dx dx)),  inlier iff |d|^2 < max_corr^2 (all f64).
 // ------------------------------------------------------------------------------------------------
-#ifndef RC_CHUNK_SZ
-#define RC_CHUNK_SZ 256
-#endif
-#ifndef RC_PACKED
-#define RC_PACKED 0   // packed f32 (v_pk_*) buys nothing here: measured equal within noise
-#endif
-#ifndef RC_SETPRIO
-#define RC_SETPRIO 1  // +2-3 %: waves about to issue MFMAs win arbitration over VALU-phase waves
-#endif
-constexpr int RC_CHUNK = RC_CHUNK_SZ;     // correspondences per LDS stage (multiple of 256)
-constexpr int RC_STG = RC_CHUNK / 256;    // staged rows per thread
-constexpr int RC_TILES = RC_CHUNK / 32;   // 32-correspondence MFMA tiles per stage
+constexpr int RC_CHUNK = 256;   // pairs per LDS stage = threads per workgroup
+constexpr int RC_HYP = 256;     // hypotheses per workgroup
+
+__device__ __forceinline__ double residual2_f64(const double (&R)[12], double sx, double sy, double sz,
+                                                double qx, double qy, double qz) {
+  const double dx = fma(R[2], sz, fma(R[1], sy, fma(R[0], sx, R[3]))) - qx;
+  const double dy = fma(R[6], sz, fma(R[5], sy, fma(R[4], sx, R[7]))) - qy;
+  const double dz = fma(R[10], sz, fma(R[9], sy, fma(R[8], sx, R[11]))) - qz;
+  return fma(dz, dz, fma(dy, dy, dx * dx));
+}
 
 // LIST: the hypotheses are the survivors of the prefilter, hlist[p][0 .. n_surv[p]) (any order).
 template <bool LIST>
-__device__ __forceinline__ void ransac_count_tile(float (*lds)[6][RC_CHUNK], const int p, const int tile,
+__device__ __forceinline__ void ransac_count_tile(double (*lds)[RC_CHUNK][6], const int p, const int tile,
                                                   const int split,
                                                   const RansacProb* __restrict__ probs,
                                                   const float* __restrict__ pk, int64_t total,
-                                                  const float* __restrict__ hyp, int it0,
-                                                  int bcount, int bmax, int splits, float thr2,
+                                                  const double* __restrict__ hyp, int it0,
+                                                  int bcount, int bmax, int splits, double thr2,
                                                   int32_t* __restrict__ res_cnt,
                                                   const int32_t* __restrict__ hlist,
                                                   const int32_t* __restrict__ n_surv) {
@@ -334,60 +333,38 @@ __device__ __forceinline__ void ransac_count_tile(float (*lds)[6][RC_CHUNK], con
   if (pr.done) return;
   const int nlist = LIST ? n_surv[p] : 0;
   if (LIST) {
-    if (tile * 128 >= nlist) return;
+    if (tile * RC_HYP >= nlist) return;
   } else {
-    if (it0 + tile * 128 >= pr.est_k || tile * 128 >= bcount) return;  // whole block beyond the bound
+    if (it0 + tile * RC_HYP >= pr.est_k || tile * RC_HYP >= bcount) return;  // whole block beyond the bound
   }
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction
-  const int half = lane >> 5;
-  const int col = lane & 31;
-  const int h0 = tile * 128 + wave * 32;                  // first hypothesis (slot) of this wave
-  const bool wave_live = LIST ? h0 < nlist : (h0 < bcount && it0 + h0 < pr.est_k);
-  const int hsel = LIST ? hlist[(int64_t)p * bmax + min(h0 + col, nlist - 1)] : h0 + col;
-  // B operands of this lane: hypothesis column h0 + col, k-slot = half
-  float b1[3], b2[3];
+  const int h = tile * RC_HYP + tid;                      // hypothesis slot of this lane
+  const bool mine = LIST ? h < nlist : (h < bcount && it0 + h < pr.est_k);
+  const int hsel = LIST ? hlist[(int64_t)p * bmax + min(h, nlist - 1)] : min(h, bmax - 1);
+  double R[12];
   {
-    const int hh = min(hsel, bmax - 1);
-    const float* hp = hyp + ((int64_t)p * 12) * bmax + hh;
+    const double* hp = hyp + ((int64_t)p * 12) * bmax + hsel;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      b1[c] = hp[(int64_t)(4 * c + half) * bmax];       // r_c0 | r_c1
-      b2[c] = hp[(int64_t)(4 * c + 2 + half) * bmax];   // r_c2 | t_c
-    }
+    for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
   }
   const int per = ((pr.m + splits - 1) / splits + RC_CHUNK - 1) / RC_CHUNK * RC_CHUNK;
   const int beg = split * per;
   const int end = min(pr.m, beg + per);
-  int cnt = 0;  // inliers of hypothesis (h0 + col) among the rows this half-wave owns
-
-  // staging: 6 arrays x 512 floats = 12 floats per thread, loaded to registers at the top of a
-  // stage and written to the other LDS buffer after the stage's compute (loads overlap the MFMAs).
-  // Rows past the range become far-away targets (never inliers).
-  float stg[6 * RC_STG];
+  int cnt = 0;
+  // staging registers: the next stage's pair of this thread is in flight while the current stage is
+  // evaluated; rows past the range become far-away targets (never inliers)
+  float stg[6];
   auto stage_load = [&](int base) {
+    const int i = base + tid;
+    const int64_t g = pr.off + (i < end ? i : 0);
 #pragma unroll
-    for (int u = 0; u < RC_STG; ++u) {
-      const int i = base + tid + 256 * u;
-      const int64_t g = pr.off + (i < end ? i : 0);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) stg[6 * u + c] = pk[(int64_t)c * total + g];  // no use yet
-    }
+    for (int c = 0; c < 6; ++c) stg[c] = pk[(int64_t)c * total + g];
   };
   auto stage_store = [&](int b, int base) {
+    const bool ok = base + tid < end;
 #pragma unroll
-    for (int u = 0; u < RC_STG; ++u) {
-      const bool ok = base + tid + 256 * u < end;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        float v = stg[6 * u + c];
-        if (c >= 3) v = -v;
-        lds[b][c][tid + 256 * u] = ok ? v : (c >= 3 ? -1.0e30f : 0.0f);
-      }
-    }
+    for (int c = 0; c < 6; ++c) lds[b][tid][c] = ok ? (double)stg[c] : (c >= 3 ? 1.0e30 : 0.0);
   };
-
   if (beg < end) {
     stage_load(beg);
     stage_store(0, beg);
@@ -397,61 +374,23 @@ __device__ __forceinline__ void ransac_count_tile(float (*lds)[6][RC_CHUNK], con
     __syncthreads();
     const bool more = base + RC_CHUNK < end;
     if (more) stage_load(base + RC_CHUNK);
-    if (wave_live) {
-#pragma unroll 1
-      for (int t = 0; t < RC_TILES; ++t) {
-        const int j0 = t * 32;
-        const float s1 = lds[buf][half][j0 + col];                   // sx | sy
-        const float s2 = half ? 1.0f : lds[buf][2][j0 + col];        // sz | 1
-        // accumulator input = -target of the 16 rows this lane owns: rows 4*half + 8g + (0..3)
-        f32x16 dx, dy, dz;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 vx = *reinterpret_cast<const float4*>(&lds[buf][3][j0 + 4 * half + 8 * g]);
-          const float4 vy = *reinterpret_cast<const float4*>(&lds[buf][4][j0 + 4 * half + 8 * g]);
-          const float4 vz = *reinterpret_cast<const float4*>(&lds[buf][5][j0 + 4 * half + 8 * g]);
-          dx[4 * g + 0] = vx.x; dx[4 * g + 1] = vx.y; dx[4 * g + 2] = vx.z; dx[4 * g + 3] = vx.w;
-          dy[4 * g + 0] = vy.x; dy[4 * g + 1] = vy.y; dy[4 * g + 2] = vy.z; dy[4 * g + 3] = vy.w;
-          dz[4 * g + 0] = vz.x; dz[4 * g + 1] = vz.y; dz[4 * g + 2] = vz.z; dz[4 * g + 3] = vz.w;
-        }
-        // d = ((( -q + r0 sx) + r1 sy) + r2 sz) + t, one rounding per step, on the matrix pipe
-#if RC_SETPRIO
-        __builtin_amdgcn_s_setprio(1);  // the wave that is ready to feed the matrix pipe goes first
-#endif
-        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[0], dx, 0, 0, 0);
-        dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[1], dy, 0, 0, 0);
-        dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b1[2], dz, 0, 0, 0);
-        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[0], dx, 0, 0, 0);
-        dy = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[1], dy, 0, 0, 0);
-        dz = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, b2[2], dz, 0, 0, 0);
-#if RC_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if RC_PACKED
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 x2 = {dx[r], dx[r + 1]}, y2 = {dy[r], dy[r + 1]}, z2 = {dz[r], dz[r + 1]};
-          const f32x2 d2 = __builtin_elementwise_fma(z2, z2, __builtin_elementwise_fma(y2, y2, x2 * x2));
-          cnt += d2[0] < thr2 ? 1 : 0;
-          cnt += d2[1] < thr2 ? 1 : 0;
-        }
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d2 = __fmaf_rn(dz[r], dz[r], __fmaf_rn(dy[r], dy[r], dx[r] * dx[r]));
-          cnt += d2 < thr2 ? 1 : 0;
-        }
-#endif
+    const int nrow = min(RC_CHUNK, end - base);
+    if (nrow == RC_CHUNK) {
+#pragma unroll 4
+      for (int j = 0; j < RC_CHUNK; ++j) {
+        const double* q = lds[buf][j];
+        cnt += residual2_f64(R, q[0], q[1], q[2], q[3], q[4], q[5]) < thr2 ? 1 : 0;
+      }
+    } else {
+      for (int j = 0; j < nrow; ++j) {
+        const double* q = lds[buf][j];
+        cnt += residual2_f64(R, q[0], q[1], q[2], q[3], q[4], q[5]) < thr2 ? 1 : 0;
       }
     }
     if (more) stage_store(buf ^ 1, base + RC_CHUNK);
     buf ^= 1;
   }
-  if (!wave_live) return;
-  cnt += __shfl_xor(cnt, 32);  // the two half-waves own disjoint correspondence rows
-  const int h = h0 + col;
-  const bool mine = LIST ? h < nlist : (h < bcount && it0 + h < pr.est_k);
-  if (half == 0 && mine) {
+  if (mine) {
     if (splits == 1)
       res_cnt[(int64_t)p * bmax + hsel] = cnt;
     else
@@ -459,25 +398,25 @@ __device__ __forceinline__ void ransac_count_tile(float (*lds)[6][RC_CHUNK], con
   }
 }
 
-// grid: x = (hypothesis tile of 128) * splits + split, y = problem.  LIST: the survivor count is only
+// grid: x = (hypothesis tile of 256) * splits + split, y = problem.  LIST: the survivor count is only
 // known on the device, so a fixed number of tile slots (gridDim.x / splits) strides over the list.
 template <bool LIST>
 __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
                                                       const float* __restrict__ pk, int64_t total,
-                                                      const float* __restrict__ hyp, int it0,
-                                                      int bcount, int bmax, int splits, float thr2,
+                                                      const double* __restrict__ hyp, int it0,
+                                                      int bcount, int bmax, int splits, double thr2,
                                                       int32_t* __restrict__ res_cnt,
                                                       const int32_t* __restrict__ hlist,
                                                       const int32_t* __restrict__ n_surv) {
-  // [buf][c][j]: c = 0..2 source xyz, c = 3..5 NEGATED target xyz (the MFMA accumulator input)
-  __shared__ __attribute__((aligned(16))) float lds[2][6][RC_CHUNK];
+  // [buf][j][c]: c = 0..2 source xyz, c = 3..5 target xyz of pair j, f64 (one 48-B row per pair)
+  __shared__ __attribute__((aligned(16))) double lds[2][RC_CHUNK][6];
   const int p = blockIdx.y;
   const int tile0 = blockIdx.x / splits;
   const int split = blockIdx.x - tile0 * splits;
   if (LIST) {
     const int nlist = n_surv[p];
     const int tstride = gridDim.x / splits;
-    for (int tile = tile0; tile * 128 < nlist; tile += tstride) {
+    for (int tile = tile0; tile * RC_HYP < nlist; tile += tstride) {
       ransac_count_tile<LIST>(lds, p, tile, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
                               res_cnt, hlist, n_surv);
       __syncthreads();  // the next tile restages LDS
@@ -500,7 +439,7 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
 // within the INFLATED threshold.  eps_h bounds |d~^2 - d^2| (k_ransac_hyp16) -- including the dropped
 // (a - a_hi) . b, bounded per hypothesis with the per-problem maxima of |b_k| -- so the sign count is an
 // UPPER bound of the exact inlier count.  Hypotheses whose bound is below the carried best get count
-// 0, the few survivors go through the exact f32 kernel: results are unchanged bit for bit.
+// 0, the few survivors go through the exact f64 kernels: results are unchanged bit for bit.
 // (The K = 48 form with a_lo . b_hi has a ~2.5x tighter eps_h but 3 MFMAs per tile: measured slower
 // end to end, DESIGN.md "What was tried".)
 // ------------------------------------------------------------------------------------------------
@@ -598,12 +537,13 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 
 // hypothesis side: row = a_hi(0..15) (f16 roundings of a) and the accumulator input
 //   c_h = |t|^2 - (thr^2 + eps_h).
-// eps_h >= |d~^2 - d^2| where d^2 is what the exact kernel computes and d~^2 the f16 pipeline
+// eps_h >= |d~^2 - d^2| where d^2 is what the exact (f64) kernels compute and d~^2 the f16 pipeline
 // c_h + sum_k a_hi_k (b_hi_k + b_lo_k):
 //   * 32 products, exact in f32; their accumulation rounds (or truncates) at most 33 times relative
 //     to sum_k |a_k b_k| <= sqrt(3) (|s| + |q| + |t|)^2 =: sqrt(3) W            <= 33 * 2^-23 * sqrt(3) W
 //   * the residuals of the hi+lo splits of b                            <= 2^-22 * sqrt(3) W + 2^-25 (2 W + 59)
-//   * the exact kernel's own f32 rounding of d^2                        <= 2^-20 W
+//   * (the exact kernels evaluated d^2 in f32 when this budget was set:   <= 2^-20 W; they are f64 now and
+//      the term is kept as slack)
 //   => < 8.3e-6 W + 1.8e-6; charged 2.5e-5 W + 6e-6 (3x margin).  The accumulation term assumes one ulp per
 //   addition; measured, the two chained MFMAs are within 2.3 ulp in total (tools/ubench/mfma_err.hip,
 //   4e8 results), so the charge is ~30x the observed error.  CS_RANSAC_CHECK runs validate the bound.
@@ -611,21 +551,21 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 //   * |R s|^2 = |s|^2 only up to the orthonormality defect E = R^T R - I:    <= 3 max|E| smax^2
 // with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
 // a zero row: every pair counts, it always survives to the exact kernel.
-__global__ void k_ransac_hyp16(const RansacProb* probs, const float* __restrict__ hyp,
+__global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
                                const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
-                               float thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
+                               double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
   const RansacProb pr = prob_view(probs, p);
   if (pr.done || it0 + h >= pr.est_k) return;
-  const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
+  const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
   double R[3][3], t[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b) R[a][b] = (double)hp[(int64_t)(4 * a + b) * bmax];
-    t[a] = (double)hp[(int64_t)(4 * a + 3) * bmax];
+    for (int b = 0; b < 3; ++b) R[a][b] = hp[(int64_t)(4 * a + b) * bmax];
+    t[a] = hp[(int64_t)(4 * a + 3) * bmax];
   }
   const double smax = (double)__uint_as_float(stat[p * PF_STAT]);
   const double tt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
@@ -668,7 +608,7 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const float* __restrict_
   const double w = 2.0 * smax + tn;
   const double eps = 2.5e-5 * w * w + 6.0e-6 + 3.0 * dev * smax * smax + 1.000001 * drop;
   // rounded towards -inf so that the f32 value never tightens the test
-  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - ((double)thr2 + eps)) : -INFINITY;
+  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - (thr2 + eps)) : -INFINITY;
 }
 
 // Upper bounds of the inlier counts.
@@ -915,14 +855,14 @@ __global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const
 // Exact counts (and fixed-point errors) when only a handful of hypotheses survive the prefilter (the
 // normal case: ~2 per problem and round).  The MFMA list kernel above needs a 128-hypothesis tile per
 // workgroup and costs ~110 us per round even for two survivors.  Here the pair range of a problem is
-// split over gridDim.x workgroups, each walks its slice once per survivor with the canonical f32
+// split over gridDim.x workgroups, each walks its slice once per survivor with the canonical f64
 // chain; integer partial sums are combined with atomics (exact, order-free).
 // grid: x = pair slice, y = problem, z = survivor slot (strided).  res_cnt / err_by_h of the survivors
 // are zero on entry.
 __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __restrict__ probs,
                                                           const float* __restrict__ pk, int64_t total,
-                                                          const float* __restrict__ hyp, int bmax,
-                                                          float thr2, float scale,
+                                                          const double* __restrict__ hyp, int bmax,
+                                                          double thr2, double scale,
                                                           int32_t* __restrict__ res_cnt,
                                                           unsigned long long* __restrict__ err_by_h,
                                                           const int32_t* __restrict__ hlist,
@@ -952,21 +892,17 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
   }
   for (int c = blockIdx.z; c < nlist; c += gridDim.z) {
     const int h = hlist[(int64_t)p * bmax + c];
-    const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
-    float R[12];
+    const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
+    double R[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
     int cnt = 0;
     unsigned long long err = 0;  // fixed-point squared error of the inliers (exact integer sum, as k_ransac_err)
     auto one = [&](float sx, float sy, float sz, float qx, float qy, float qz) {
-      // same chain as the MFMA pair: fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q))))
-      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -qx))) + R[3];
-      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -qy))) + R[7];
-      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -qz))) + R[11];
-      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+      const double d2 = residual2_f64(R, (double)sx, (double)sy, (double)sz, (double)qx, (double)qy, (double)qz);
       if (d2 < thr2) {
         ++cnt;
-        err += (unsigned long long)(uint32_t)(d2 * scale);
+        err += (unsigned long long)(d2 * scale);
       }
     };
     if (in_regs) {
@@ -1102,9 +1038,9 @@ __global__ __launch_bounds__(256) void k_ransac_scan1(RansacProb* probs, int n_p
 // Fixed-point squared error of the candidate hypotheses: grid (slots, problems).
 __global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict__ probs,
                                                     const float* __restrict__ pk, int64_t total,
-                                                    const float* __restrict__ hyp, int bmax,
-                                                    const int32_t* __restrict__ cand, float thr2,
-                                                    float scale,
+                                                    const double* __restrict__ hyp, int bmax,
+                                                    const int32_t* __restrict__ cand, double thr2,
+                                                    double scale,
                                                     unsigned long long* __restrict__ cand_err) {
   __shared__ unsigned long long red[256];
   const int p = blockIdx.y;
@@ -1112,20 +1048,17 @@ __global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict
   const int tid = threadIdx.x;
   for (int c = blockIdx.x; c < pr.n_cand; c += gridDim.x) {
     const int h = cand[(int64_t)p * bmax + c];
-    const float* hp = hyp + ((int64_t)p * 12) * bmax + h;
-    float R[12];
+    const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
+    double R[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
     unsigned long long err = 0;
     for (int i = tid; i < pr.m; i += 256) {
       const int64_t g = pr.off + i;
-      const float sx = pk[0 * total + g], sy = pk[1 * total + g], sz = pk[2 * total + g];
-      // same chain as the MFMA pair: fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q))))
-      const float dx = __fmaf_rn(R[2], sz, __fmaf_rn(R[1], sy, __fmaf_rn(R[0], sx, -pk[3 * total + g]))) + R[3];
-      const float dy = __fmaf_rn(R[6], sz, __fmaf_rn(R[5], sy, __fmaf_rn(R[4], sx, -pk[4 * total + g]))) + R[7];
-      const float dz = __fmaf_rn(R[10], sz, __fmaf_rn(R[9], sy, __fmaf_rn(R[8], sx, -pk[5 * total + g]))) + R[11];
-      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-      if (d2 < thr2) err += (unsigned long long)(uint32_t)(d2 * scale);
+      const double d2 = residual2_f64(R, (double)pk[0 * total + g], (double)pk[1 * total + g],
+                                      (double)pk[2 * total + g], (double)pk[3 * total + g],
+                                      (double)pk[4 * total + g], (double)pk[5 * total + g]);
+      if (d2 < thr2) err += (unsigned long long)(d2 * scale);
     }
     red[tid] = err;
     __syncthreads();
@@ -1140,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict
 
 // cand_err is indexed by candidate slot (k_ransac_err) or, when by_h is set, by hypothesis
 // (k_ransac_count_few computed the error of every survivor along with its count)
-__global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const float* __restrict__ hyp,
+__global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const double* __restrict__ hyp,
                                const int32_t* __restrict__ cand,
                                const unsigned long long* __restrict__ cand_err, int by_h, int it0,
                                int bmax) {
@@ -1175,7 +1108,7 @@ __global__ void k_ransac_finish(const RansacProb* __restrict__ probs, int n_prob
   const RansacProb pr = probs[p];
   float* o = T + (int64_t)p * 16;
   if (pr.best_cnt > 0) {
-    for (int c = 0; c < 12; ++c) o[c] = pr.best_T[c];
+    for (int c = 0; c < 12; ++c) o[c] = (float)pr.best_T[c];  // the reference's T_est.astype(np.float32)
   } else {
     for (int c = 0; c < 12; ++c) o[c] = (c % 5 == 0) ? 1.f : 0.f;
   }
@@ -1231,13 +1164,13 @@ void cs_ransac_prefilter_stats(uint64_t out[5], int reset) {
 }
 
 int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off, int n_prob,
-                    float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
+                    double max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
                     float* d_T, int32_t* d_inliers, double* d_rmse, int32_t* d_iters,
                     void* stream) {
   CS_REQUIRE(h_off && d_T, CS_ERR_INVALID, "cs_ransac_batch: NULL argument");
   CS_REQUIRE(ransac_n >= 3 && ransac_n <= 64, CS_ERR_INVALID,
              "cs_ransac_batch: ransac_n %d not in [3, 64]", ransac_n);
-  CS_REQUIRE(max_corr > 0.f && max_iter >= 1, CS_ERR_INVALID,
+  CS_REQUIRE(max_corr > 0.0 && max_iter >= 1, CS_ERR_INVALID,
              "cs_ransac_batch: need max_corr > 0 and max_iter >= 1");
   CS_REQUIRE(confidence > 0.0 && confidence <= 1.0, CS_ERR_INVALID,
              "cs_ransac_batch: confidence must be in (0, 1]");
@@ -1252,7 +1185,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   int m_max = 0;
   for (int p = 0; p < n_prob; ++p) {
     int64_t m = h_off[p + 1] - h_off[p];
-    CS_REQUIRE(m >= 0 && m < (1LL << 31), CS_ERR_INVALID, "cs_ransac_batch: bad segment %d", p);
+    CS_REQUIRE(m >= 0 && m < (1LL << 24), CS_ERR_INVALID,
+               "cs_ransac_batch: bad segment %d (a problem holds fewer than 2^24 correspondences)", p);
     RansacProb& pr = hp[p];
     memset(&pr, 0, sizeof(pr));
     pr.off = h_off[p];
@@ -1289,7 +1223,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   CS_REQUIRE(state.p && h_state, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   PoolBuf<float> pk((size_t)tot1 * 6);
   PoolBuf<float4> pair32((size_t)tot1 * 2);
-  PoolBuf<float> hyp((size_t)2 * n_prob * 12 * bmax);  // hypotheses, one set per round parity
+  PoolBuf<double> hyp((size_t)2 * n_prob * 12 * bmax);  // hypotheses (f64 R|t), one set per round parity
   PoolBuf<int32_t> res_cnt((size_t)n_prob * bmax), cand((size_t)n_prob * bmax);
   PoolBuf<unsigned long long> cand_err((size_t)n_prob * bmax);
   CS_REQUIRE(pk.p && pair32.p && hyp.p && res_cnt.p && cand.p && cand_err.p,
@@ -1331,11 +1265,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                        d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
     CS_LAUNCH_CHECK();
   }
-  // squared threshold and power-of-two fixed-point scale (thr2 * scale <= 2^31)
-  const float thr2 = max_corr * max_corr;
+  // squared threshold (Open3D: max_correspondence_distance * max_correspondence_distance in double) and
+  // the power-of-two fixed-point scale of the inlier error: terms d^2 * scale < 2^38, so the u64 sum over
+  // a problem's (< 2^24) pairs cannot overflow and is exact in any order
+  const double thr2 = max_corr * max_corr;
   int ex = 0;
-  (void)frexpf(thr2, &ex);
-  const float scale = ldexpf(1.0f, 31 - ex);
+  (void)frexp(thr2, &ex);
+  const double scale = ldexp(1.0, 38 - ex);
   const double log_1mc = log(1.0 - confidence);  // -inf when confidence == 1: never exits early
   unsigned long long tot_surv = 0, tot_eval = 0;
   const int trace_it0 = getenv("CS_PF_TRACE") ? atoi(getenv("CS_PF_TRACE")) : -1;
@@ -1408,7 +1344,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       for (size_t i = 0; i < lists[x].size(); ++i) tab[(size_t)x * pslots + i] = lists[x][i];
     int32_t* xcd_prob = xcd_buf.p + (size_t)par * 8 * n_prob;
     (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, st);
-    float* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
+    double* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
     {
       ProfScope prof("ransac_hyp", st);
       const int htiles = (b + 255) / 256;
@@ -1455,14 +1391,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   while (true) {
     const int it0 = cur.it0, b = cur.b;
     const bool pf = cur.pf;
-    const float* hyp_r = hyp.p + (size_t)cur.par * n_prob * 12 * bmax;
+    const double* hyp_r = hyp.p + (size_t)cur.par * n_prob * 12 * bmax;
     const int32_t* cnt_up_r = cnt_up.p + (size_t)cur.par * n_prob * bmax;
     if (cur.on_side) {
       CS_HIP_CHECK(hipStreamWaitEvent(s, front_done[cur.par].e, 0));
       side_pending = false;
     }
     bool err_known = false;  // the fixed-point errors of all candidates are already in cand_err (by hypothesis)
-    const int tiles = (b + 127) / 128;
+    const int tiles = (b + RC_HYP - 1) / RC_HYP;
     // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
     // chunk is small (integer partial sums combine exactly)
     int splits = (int)(4096 / ((int64_t)n_prob * tiles > 0 ? (int64_t)n_prob * tiles : 1));
@@ -1471,8 +1407,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     while (splits > 1 && m_max / splits < 4 * RC_CHUNK) --splits;
     CS_HIP_CHECK(hipMemsetAsync(d_nsurv, 0, st_surv + 8, s));  // survivor counts and n_active
     // algorithmic work of this chunk (hp is the state before it): 30 FLOP per (evaluated hypothesis,
-    // correspondence) for the exact count (transform 18 + squared distance 8 + compare/accumulate,
-    // SURVEY 8d), 64 for the prefilter (the 32 multiply-adds of the a_hi (b_hi + b_lo) expansion)
+    // correspondence) (transform 18 + squared distance 8 + compare/accumulate) -- for the
+    // exact count and for the prefilter alike (its matrix pipe executes 64 per pair: the 32
+    // multiply-adds of the a_hi (b_hi + b_lo) expansion)
     double eval_pairs = 0.0;
     for (int p = 0; p < n_prob; ++p) {
       if (hp[p].done) continue;
@@ -1598,7 +1535,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                "cs_ransac_batch: prefilter bound violated for %llu hypotheses", h_stats[0]);
   }
   hipLaunchKernelGGL(k_ransac_finish, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                     d_probs, n_prob, (double)scale, d_T, d_inliers, d_rmse, d_iters);
+                     d_probs, n_prob, scale, d_T, d_inliers, d_rmse, d_iters);
   CS_LAUNCH_CHECK();
   CS_HIP_CHECK(hipStreamSynchronize(s));
   side_drain.clean = true;

@@ -208,14 +208,17 @@ int cs_hausdorff_1dir(const float* d_src, const int64_t* h_soff, const float* d_
  * Semantics = Open3D's loop run on one thread, with a counter-based RNG:
  *   for itr in [0, max_iter): stop if itr >= est_k; sample ransac_n pairs (with replacement,
  *   idx = rng(seed, itr, j) mod-free multiply-shift); T = rigid least-squares fit (no scale);
- *   inliers = #{ |T src_i - tgt_i|^2 < max_corr^2 }, err = sum of inlier squared distances;
+ *   inliers = #{ |T src_i - tgt_i|^2 < max_corr^2 }, err = sum of inlier squared distances -- T, the
+ *   transform of the points and the comparison in f64, as Open3D evaluates them (the reference
+ *   converts the points to float64, utils/eval_pose.py:83-86; max_corr is the Python float);
  *   better = more inliers, or equal inliers and smaller err; on improvement
  *   est_k = min(est_k, ceil(log(1-confidence) / log(1 - (inliers/M)^ransac_n))).
- * d_T f32 [n_prob,16] row-major 4x4 (identity if no hypothesis had an inlier);
+ * d_T f32 [n_prob,16] row-major 4x4 = the best f64 transform cast once at the end, where the reference
+ * casts it (utils/symmetry.py:274) (identity if no hypothesis had an inlier);
  * d_inliers int32 [n_prob]; d_rmse f64 [n_prob]; d_iters int32 [n_prob] = iterations consumed.
  * ---------------------------------------------------------------------------------------- */
 int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off, int n_prob,
-                    float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
+                    double max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
                     float* d_T, int32_t* d_inliers, double* d_rmse, int32_t* d_iters,
                     void* stream);
 /* Diagnostics of the inlier-count prefilter inside cs_ransac_batch (an f16 matrix-core pass that

@@ -327,9 +327,12 @@ void oc_rigid_fit(const double* ps, const double* pt, int n, double* R, double* 
  * RegistrationRANSACBasedOnCorrespondence as the reference calls it (utils/eval_pose.py:82-100:
  * identity correspondences, ransac_n = 10, defaults max_iteration 100000 / confidence 0.999,
  * point-to-point without scaling, no checkers) run on ONE thread, with the counter-based RNG.
- * Evaluation arithmetic in f32 (fmaf chains below), inlier error in fixed point.
+ * Evaluation arithmetic in f64 like Open3D's (the reference hands it float64 points,
+ * utils/eval_pose.py:83-86; Matrix4d * Vector4d, squaredNorm and the comparison with
+ * max_correspondence_distance^2 are double), inlier error in fixed point (exact, order-free sums).
+ * The best transform is cast to f32 at the end, where the reference casts it (utils/symmetry.py:274).
  * ---------------------------------------------------------------------------------------- */
-void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, int ransac_n,
+void oc_ransac(const float* src, const float* tgt, int64_t m, double max_corr, int ransac_n,
                int max_iter, double confidence, uint64_t seed, float* T16, int32_t* inliers,
                double* rmse, int32_t* iters) {
   for (int c = 0; c < 16; ++c) T16[c] = (c % 5 == 0) ? 1.0f : 0.0f;
@@ -337,15 +340,15 @@ void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, in
   *rmse = 0.0;
   *iters = 0;
   if (m < ransac_n) return;
-  const float thr2 = max_corr * max_corr;
+  const double thr2 = max_corr * max_corr;
   int ex = 0;
-  (void)frexpf(thr2, &ex);
-  const float scale = ldexpf(1.0f, 31 - ex);
+  (void)frexp(thr2, &ex);
+  const double scale = ldexp(1.0, 38 - ex); /* terms < 2^38, fewer than 2^24 pairs: the u64 sum is exact */
   const double log_1mc = log(1.0 - confidence);
   int est_k = max_iter;
   int best_cnt = 0;
   uint64_t best_err = 0;
-  float bestT[12];
+  double bestT[12];
   double ps[64 * 3], pt[64 * 3];
   int itr = 0;
   for (; itr < max_iter; ++itr) {
@@ -359,25 +362,22 @@ void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, in
     }
     double Rd[9], td[3];
     oc_rigid_fit(ps, pt, ransac_n, Rd, td);
-    float R[9], t[3];
-    for (int a = 0; a < 9; ++a) R[a] = (float)Rd[a];
-    for (int a = 0; a < 3; ++a) t[a] = (float)td[a];
+    const double* R = Rd;
+    const double* t = td;
     int cnt = 0;
     uint64_t err = 0;
     /* integer sums: the thread split does not change the result */
 #pragma omp parallel for reduction(+ : cnt, err) schedule(static) if (m >= 8192)
     for (int64_t i = 0; i < m; ++i) {
-      const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-      /* canonical order of the residual d = R s + t - q: start from -q, add the x, y, z terms,
-       * then the translation, one rounding per step
-       * (= fma(t,1, fma(r2,sz, fma(r1,sy, fma(r0,sx,-q)))), the chain an f32 MFMA evaluates) */
-      const float dx = fmaf(R[2], sz, fmaf(R[1], sy, fmaf(R[0], sx, -tgt[3 * i]))) + t[0];
-      const float dy = fmaf(R[5], sz, fmaf(R[4], sy, fmaf(R[3], sx, -tgt[3 * i + 1]))) + t[1];
-      const float dz = fmaf(R[8], sz, fmaf(R[7], sy, fmaf(R[6], sx, -tgt[3 * i + 2]))) + t[2];
-      const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+      /* canonical chain: p = R s + t accumulated from the translation, d = p - q, all f64 */
+      const double dx = fma(R[2], sz, fma(R[1], sy, fma(R[0], sx, t[0]))) - (double)tgt[3 * i];
+      const double dy = fma(R[5], sz, fma(R[4], sy, fma(R[3], sx, t[1]))) - (double)tgt[3 * i + 1];
+      const double dz = fma(R[8], sz, fma(R[7], sy, fma(R[6], sx, t[2]))) - (double)tgt[3 * i + 2];
+      const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
       if (d2 < thr2) {
         cnt += 1;
-        err += (uint64_t)(uint32_t)(d2 * scale);
+        err += (uint64_t)(d2 * scale);
       }
     }
     if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && err < best_err)) {
@@ -403,14 +403,14 @@ void oc_ransac(const float* src, const float* tgt, int64_t m, float max_corr, in
   *iters = itr;
   *inliers = best_cnt;
   if (best_cnt > 0) {
-    for (int c = 0; c < 12; ++c) T16[c] = bestT[c];
-    *rmse = sqrt(((double)best_err / (double)scale) / (double)best_cnt);
+    for (int c = 0; c < 12; ++c) T16[c] = (float)bestT[c];
+    *rmse = sqrt(((double)best_err / scale) / (double)best_cnt);
   }
 }
 
 /* Batched front end used for CPU-baseline timing: problems are independent, one per OpenMP task. */
 void oc_ransac_batch(const float* src, const float* tgt, const int64_t* off, int n_prob,
-                     float max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
+                     double max_corr, int ransac_n, int max_iter, double confidence, uint64_t seed,
                      float* T, int32_t* inliers, double* rmse, int32_t* iters) {
 #pragma omp parallel for schedule(dynamic, 1)
   for (int p = 0; p < n_prob; ++p)

@@ -58,9 +58,9 @@ def load():
         lib.oc_chamfer_1dir.restype = c_double
         lib.oc_rng_indices.argtypes = [c_uint64, c_uint64, c_int, c_uint32, vp]
         lib.oc_rigid_fit.argtypes = [vp, vp, c_int, vp, vp]
-        lib.oc_ransac.argtypes = [vp, vp, c_int64, c_float, c_int, c_int, c_double, c_uint64, vp,
+        lib.oc_ransac.argtypes = [vp, vp, c_int64, c_double, c_int, c_int, c_double, c_uint64, vp,
                                   POINTER(c_int32), POINTER(c_double), POINTER(c_int32)]
-        lib.oc_ransac_batch.argtypes = [vp, vp, vp, c_int, c_float, c_int, c_int, c_double,
+        lib.oc_ransac_batch.argtypes = [vp, vp, vp, c_int, c_double, c_int, c_int, c_double,
                                         c_uint64, vp, vp, vp, vp]
         lib.oc_symcut_fit_one.argtypes = [vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_uint64, vp, vp, POINTER(c_double), POINTER(c_double), vp]

@@ -287,6 +287,60 @@ def test_ransac_oracle_recovers_pose_and_exits_early(oracle_native):
     assert np.array_equal(Ti, np.eye(4, dtype=np.float32)) and inl0 == 0 and it0 == 0
 
 
+def test_ransac_oracle_equals_an_independent_f64_replay(oracle_native):
+    """Independent check of oc_ransac (it lands with every edit of that function):
+    a plain NumPy replay of Open3D's single-thread loop in float64 -- samples from the counter RNG,
+    SVD (Umeyama, no scaling) fit instead of the Horn quaternion, `(R @ s.T).T + t - q` with ordinary
+    matmul instead of the fma chain, the comparison with the DOUBLE max_corr ** 2, better = more inliers
+    or equal inliers and smaller rmse, est_k from Open3D's formula -- must select the same iteration,
+    count, iteration total and (to 1e-6) transform.  The number of (hypothesis, pair) decisions an f32
+    evaluation (the oracle's arithmetic before round 2) would flip is printed (-s)."""
+    from corsair_amd import synth
+
+    rng = np.random.default_rng(21)
+    for trial, (m, frac, max_corr, max_iter) in enumerate([(700, 0.5, 0.2, 1500), (1200, 0.25, 0.05, 2500),
+                                                           (400, 0.8, 0.1, 1000)]):
+        src = rng.uniform(-0.8, 0.8, (m, 3)).astype(np.float32)
+        T = synth.random_pose(60 + trial, max_trans=0.4)
+        tgt = (synth.apply_pose(src, T) + rng.normal(0, 0.02, (m, 3))).astype(np.float32)
+        bad = rng.random(m) > frac
+        tgt[bad] = rng.uniform(-1.2, 1.2, (int(bad.sum()), 3)).astype(np.float32)
+        Te, inl, rmse, iters = oracle_native.ransac(src, tgt, max_corr, 10, max_iter, 0.999, 3)
+
+        S, Q = src.astype(np.float64), tgt.astype(np.float64)
+        thr2 = max_corr * max_corr
+        best = (0, np.inf, None, -1)
+        est_k, itr, n_diff32 = max_iter, 0, 0
+        while itr < max_iter and itr < est_k:
+            idx = oracle_native.rng_indices(3, itr, 10, m)
+            ps, pt = S[idx], Q[idx]
+            cs, ct = ps.mean(0), pt.mean(0)
+            U, _, Vt = np.linalg.svd((pt - ct).T @ (ps - cs))
+            D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+            R = U @ D @ Vt
+            t = ct - R @ cs
+            d2 = (((R @ S.T).T + t - Q) ** 2).sum(1)
+            ok = d2 < thr2
+            cnt = int(ok.sum())
+            R32, t32 = R.astype(np.float32), t.astype(np.float32)
+            d2_32 = (((src @ R32.T) + t32 - tgt) ** 2).sum(1, dtype=np.float32)
+            n_diff32 += int(((d2_32 < np.float32(max_corr) ** 2) != ok).sum())
+            err = float(d2[ok].sum())
+            if cnt > best[0] or (cnt == best[0] and cnt > 0 and err < best[1]):
+                best = (cnt, err, np.concatenate([R, t[:, None]], 1), itr)
+                ratio = min(1.0, cnt / m)
+                den = np.log(1.0 - ratio ** 10) if ratio < 1 else -np.inf
+                if den < 0:
+                    k = np.log(1 - 0.999) / den
+                    if k < est_k:
+                        est_k = int(np.ceil(k))
+            itr += 1
+        assert inl == best[0] and iters == itr, (trial, inl, best[0], iters, itr)
+        assert np.abs(Te[:3, :4].astype(np.float64) - best[2]).max() < 1e-6
+        assert rmse == pytest.approx(np.sqrt(best[1] / best[0]), rel=1e-9)
+        print("trial", trial, "iterations", itr, "(hypothesis, pair) decisions an f32 evaluation flips:", n_diff32)
+
+
 def test_symmetric_cut_on_four_legged_object(oracle_native):
     """Part cut on a synthetic 4-fold object whose features encode the height: the 50 feature-NN of
     a leg anchor are the four leg tips -> K=4 k-means finds the four legs, the gate accepts, the
