@@ -150,11 +150,101 @@ def pose_losses(T_est, T0s, T1s, syms):
     return np.asarray(t_l), np.asarray(r_l)
 
 
+# ---- the evaluation entry (evaluation.py:207-441) ---------------------------------------------------------
+@dataclass
+class EvalResult:
+    """Everything App.__init__ of evaluation.py computes after the model is loaded."""
+    stat: dict                      # precision, top1_error, top1_predict, gt (evaluation.py:272-283)
+    per_query: dict                 # the nine arrays of evaluation.py:421-441 (cache.NAMES)
+    ransac: dict                    # aggregate() of the vanilla RANSAC poses (evaluation.py:334-358)
+    sym: dict                       # aggregate() of the symmetry-aided poses
+    sym_success_rate: float
+    from_cache: bool
+    report: str                     # the log block of evaluation.py:359-383
+
+
+def _report(ransac, sym, rate):
+    def block(title, a, tail):
+        return (f"\n==================================================================\n"
+                f"{title}:\n"
+                f"translation error: {a['rte_mean']},\n"
+                f"rte 0.02: {a['rte_002']}, rte 0.05: {a['rte_005']}, rte 0.10: {a['rte_010']}, rte 0.15: {a['rte_015']}\n"
+                f"------------------------------------------------------------------\n"
+                f"rotation error: {a['rre_mean_rad']},\n"
+                f"rre 5: {a['rre_5']}, rre 15: {a['rre_15']}, rre 45: {a['rre_45']},\n"
+                f"chamfer distance: {a['chamfer_mean']}" + tail)
+
+    return (block("vanilla ransac", ransac, "") +
+            block("sym ransac", sym, "\n==================================================================\n") +
+            f"\nsym success rate: {rate}")
+
+
+def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, category="chair",
+             register_top1=True, cache_dir=None, ignore_cache=False, force_gate=False, batch_size=None):
+    """The reference's evaluation, end to end (evaluation.py:207-441), on the MI355X path.
+
+    catalog / queries: lists of f32 [n,3] clouds (already normalised) or EmbeddedSets; best_match int
+    [Q] (annotated CAD of every query), table f64 [C,C] pairwise Chamfer of the catalog (diag 0),
+    base_T [Q,4,4] / lib_T [C,4,4] ground-truth poses (`base_T`, `pos_T` of the datasets), syms int [C].
+      1. feature extraction of both sets in batches (evaluation.py:213-269),
+      2. scan2cad_retrieval_eval with Precision@M = 0.1 C (evaluation.py:272-283),
+      3. registration of every query against its top-1 prediction (or the GT CAD) with sym_pose, and
+         eval_pose of both estimates (evaluation.py:297-331) -- batched, not one Python iteration each;
+         skipped when the nine cache files exist (evaluation.py:287, _load_data),
+      4. aggregation + the log block (evaluation.py:334-383), 5. the result cache (evaluation.py:421-441).
+    Returns an EvalResult."""
+    from . import cache as C_
+    from .utils import retrieval
+
+    cfg = pipe.cfg
+    bs = batch_size or cfg.batch_size
+    cat = catalog if isinstance(catalog, EmbeddedSet) else pipe.embed_clouds(catalog, bs)
+    qs = queries if isinstance(queries, EmbeddedSet) else pipe.embed_clouds(queries, bs)
+    Q, C = len(qs), len(cat)
+    best_match = np.asarray(best_match).astype(np.int64)
+    syms = np.asarray(syms)
+    stat = retrieval.scan2cad_retrieval_eval(qs.desc, cat.desc, best_match, table, int(0.1 * np.asarray(table).shape[1]))
+
+    per_query = None if (ignore_cache or cache_dir is None) else C_.load_results(cache_dir, category, register_top1)
+    from_cache = per_query is not None
+    if per_query is None:
+        pos_idx = np.asarray(stat["top1_predict" if register_top1 else "gt"], dtype=np.int64)
+        out = {k: [] for k in C_.NAMES}
+        for s in range(0, Q, bs):
+            ids = np.arange(s, min(Q, s + bs))
+            q = qs.gather(ids)
+            cads = cat.gather(pos_idx[ids])
+            cad_sym = syms[pos_idx[ids]]
+            res = pipe.register(q, cads, cad_sym, anchor_ids=[(2 * int(i), 2 * int(i) + 1) for i in ids],
+                                force_gate=force_gate)
+            Tr, Tb, cdr, cdb = (t.cpu().numpy() for t in (res.T_ransac, res.T_best, res.cd_ransac, res.cd_best))
+            T0 = [base_T[i] for i in ids]
+            T1 = [lib_T[j] for j in pos_idx[ids]]
+            t_r, r_r = pose_losses(Tr, T0, T1, cad_sym)
+            t_s, r_s = pose_losses(Tb, T0, T1, cad_sym)
+            for k, v in (("Ts_est_ransac", Tr), ("Ts_est_best", Tb), ("t_losses_ransac", t_r),
+                         ("t_losses_sym", t_s), ("r_losses_ransac", r_r), ("r_losses_sym", r_s),
+                         ("sym_ransac_success", res.ok), ("chamfer_dist_ransac", cdr), ("chamfer_dist_sym", cdb)):
+                out[k].append(np.asarray(v))
+        per_query = {k: np.concatenate(v) for k, v in out.items()}
+        if cache_dir is not None:
+            C_.save_results(cache_dir, category, register_top1, per_query)
+
+    ransac = aggregate(per_query["r_losses_ransac"], per_query["t_losses_ransac"], per_query["chamfer_dist_ransac"])
+    sym = aggregate(per_query["r_losses_sym"], per_query["t_losses_sym"], per_query["chamfer_dist_sym"])
+    for a, r in ((ransac, per_query["r_losses_ransac"]), (sym, per_query["r_losses_sym"])):
+        a["rre_mean_rad"] = float(np.mean(np.asarray(r, np.float64)))
+    rate = float(np.mean(per_query["sym_ransac_success"]))
+    return EvalResult(stat, per_query, ransac, sym, rate, from_cache, _report(ransac, sym, rate))
+
+
 # ---- synthetic Scan2CAD-shaped workload ---------------------------------------------------------------
 @dataclass
 class SyntheticScan2CAD:
-    """Chair-sized synthetic evaluation set: C catalog clouds, Q queries = posed copies of catalog
-    clouds (known GT pose), symmetry labels with the chair label statistics (SURVEY 2 #28)."""
+    """Chair-sized synthetic evaluation set, the input of run_eval when the Scan2CAD annotations are
+    not available: C catalog clouds, Q queries = posed copies of catalog clouds (known GT pose),
+    symmetry labels with the chair label statistics; `table()` computes the pairwise
+    Chamfer table the retrieval metric needs (utils/pc_dist.py, 2000 points per cloud)."""
     n_catalog: int = 652
     n_query: int = 993
     n_points: int = 10000
@@ -184,3 +274,16 @@ class SyntheticScan2CAD:
             self.query_T.append(T)
             self.query_cad.append(cad)
         return self
+
+    def table(self, n_points=2000):
+        from .utils import pc_dist
+
+        t = pc_dist.compute_dist([c[:n_points] for c in self.catalog])
+        np.fill_diagonal(t, 0.0)                     # datasets/ScannetDataset.py:65-66
+        return t
+
+    def eval_inputs(self):
+        """(catalog, queries, best_match, base_T, lib_T, syms) for run_eval; the CADs sit in their
+        canonical frame (lib_T = identity, like the bench's T1)."""
+        return (self.catalog, self.queries, np.asarray(self.query_cad), np.stack(self.query_T),
+                np.stack([np.eye(4)] * len(self.catalog)), self.sym)
