@@ -69,6 +69,7 @@ def _declare(lib):
         "cs_prof_get": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),
         "cs_prof_get_units": (c_int, [c_char_p, POINTER(c_double)]),
         "cs_pool_trim": (None, []),
+        "cs_pool_stats": (None, [POINTER(c_uint64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

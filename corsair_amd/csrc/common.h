@@ -34,6 +34,7 @@ void set_error(const char* fmt, ...);
 // Size-class caching device allocator for library-owned scratch and map storage.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
+void pool_stats(unsigned long long out[3]);
 void pool_use_stream(hipStream_t s);
 // device -> host through the thread's page-locked staging buffer (runtime.hip); sync hands the bytes out
 hipError_t download_async(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s);

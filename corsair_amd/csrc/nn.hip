@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------
-// The same shortlist on the f16 matrix cores (d = 64 / 128 / 256, k <= 10): 16x the f64 matrix rate.
+// The same shortlist on the f16 matrix cores (d = 64 / 128 / 256 / 512, k <= 10): 16x the f64 matrix rate.
 // s~ = |x|^2 - 2 q.x with x = x_hi + x_lo and v = -2 q = v_hi + v_lo split into f16 (the lo * lo
 // products are dropped): 3 v_mfma_f32_32x32x16_f16 per 16 features of a 32 x 32 (catalog x query) tile,
 // accumulator preloaded with |x|^2.  Queries live in registers (32 per wave, 8 waves per workgroup:
@@ -1179,9 +1179,15 @@ __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ 
 // and VERIFIED -- every row outside the shortlist has s~ >= tau (the smallest of the lanes' TKF_KK-th
 // values), hence exact s >= tau - eps with eps = (3 d + 4) 2^-22 (|q|^2 + max |x|^2) bounding the f16
 // pipeline error (split residuals 3 * 2^-21 |q||x|, 3 d + 1 f32 accumulations of partial sums
-// <= |x|^2 + 2 |q||x|); queries whose exact k-th value is not below that go through the f64 path.
+// <= |x|^2 + 2 |q||x|) plus an ABSOLUTE term 2^-24 sqrt(d) (2|q| + max|x|) for elements whose hi or lo part
+// is an f16 subnormal (spacing 2^-24 whatever the magnitude: descriptors with norms << 1);
+// queries whose exact k-th value is not below that go through the f64 path.
+// d = 512 (TERMS = 2): the 32 queries of a wave would need 256 VGPRs for hi + lo operands, so only v_hi is
+// kept in registers (128 VGPRs) and the x_hi v_lo term is dropped as well -- 2 MFMAs per 16 features, and
+// eps grows by its bound 1.001 * 2^-10 |q| max|x| (about 1e-3 for unit descriptors, against a gap of ~0.1
+// between the k-th neighbour and the shortlist threshold on the C5 data); 32-row stages (2 x 64.5 KiB of LDS).
 // ------------------------------------------------------------------------------------------
-constexpr int TKF_ROWS = 64;   // catalog rows per LDS stage (2 MFMA row tiles)
+constexpr int TKF_ROWS = 64;   // catalog rows per LDS stage (2 MFMA row tiles); the image is padded to whole 64s
 constexpr int TKF_QT = 256;    // queries per workgroup (8 waves x 32)
 constexpr int TKF_KK = 12;     // shortlist per lane (two lanes per query and catalog split)
 
@@ -1223,17 +1229,19 @@ __global__ void k_max_bits(const double* __restrict__ v, int64_t n, unsigned* __
 
 // grid: x = query tile (TKF_QT), y = catalog split; 512 threads; dynamic LDS: 2 stages + 2 x TKF_ROWS floats.
 // cand_i: [nq][nsplit * 2][TKF_KK], tau: [nq][nsplit * 2]
-template <int DCH>
+template <int DCH, int TERMS, int ROWS>
 __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ qimg, int64_t nq,
                                                   const _Float16* __restrict__ ximg, int64_t nx,
                                                   const double* __restrict__ xn, int nsplit,
                                                   int* __restrict__ cand_i, float* __restrict__ tau) {
   constexpr int PITCH_B = DCH * 64 + 16;              // bytes per image row
-  constexpr int STAGE_BYTES = TKF_ROWS * PITCH_B;     // whole KiB for DCH = 4, 8, 16
-  constexpr int STAGE_KIB = STAGE_BYTES / 1024;
-  static_assert(STAGE_BYTES % 1024 == 0, "a stage must be whole 1-KiB LDS-DMA instructions");
+  constexpr int STAGE_BYTES = ROWS * PITCH_B;         // whole KiB for DCH = 4, 8, 16; 64.5 KiB for DCH = 32
+  constexpr int STAGE_PIECES = (STAGE_BYTES + 1023) / 1024;   // 1-KiB LDS-DMA instructions (the last may be partial)
+  constexpr int STAGE_PITCH = STAGE_PIECES * 1024;
+  constexpr int NT = ROWS / 32;                       // MFMA row tiles per stage
+  static_assert(STAGE_BYTES % 16 == 0 && ROWS % 32 == 0 && TKF_ROWS % ROWS == 0, "stage shape");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  float* tn_s = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES);  // [2][TKF_ROWS]
+  float* tn_s = reinterpret_cast<float*>(lds + 2 * STAGE_PITCH);  // [2][ROWS]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1244,13 +1252,13 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
   const int64_t xb = (int64_t)blockIdx.y * per;
   const int64_t xe = min(nx, xb + per);
   // B operands of the wave's 32 queries: lane supplies k = 8 half .. +8 of every 16-feature chunk
-  f16x8 qh[DCH], ql[DCH];
+  f16x8 qh[DCH], ql[TERMS == 3 ? DCH : 1];
   {
     const _Float16* qrow = qimg + (my_q < nq ? my_q : 0) * (int64_t)(DCH * 32) + 8 * half;
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
       qh[c] = *reinterpret_cast<const f16x8*>(qrow + c * 32);
-      ql[c] = *reinterpret_cast<const f16x8*>(qrow + c * 32 + 16);
+      if (TERMS == 3) ql[c] = *reinterpret_cast<const f16x8*>(qrow + c * 32 + 16);
     }
   }
   float bd[TKF_KK];
@@ -1264,45 +1272,46 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
   auto issue_stage = [&](int b, int64_t base) {
     const char* gp = gimg + base * PITCH_B;
 #pragma unroll
-    for (int i = 0; i < (STAGE_KIB + 7) / 8; ++i) {
+    for (int i = 0; i < (STAGE_PIECES + 7) / 8; ++i) {
       const int piece = wave + 8 * i;  // wave-uniform
-      if (piece < STAGE_KIB)
+      // (the last piece of a 64.5-KiB stage is half a KiB: the upper lanes sit it out)
+      if (piece < STAGE_PIECES && piece * 1024 + lane * 16 < STAGE_BYTES)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024),
-                                         (__attribute__((address_space(3))) void*)(lds + b * STAGE_BYTES + piece * 1024),
+                                         (__attribute__((address_space(3))) void*)(lds + b * STAGE_PITCH + piece * 1024),
                                          16, 0, 0);
     }
-    if (tid < TKF_ROWS) tn_s[b * TKF_ROWS + tid] = base + tid < xe ? (float)xn[base + tid] : INFINITY;
+    if (tid < ROWS) tn_s[b * ROWS + tid] = base + tid < xe ? (float)xn[base + tid] : INFINITY;
   };
   if (xb < xe) issue_stage(0, xb);
   int buf = 0;
-  for (int64_t base = xb; base < xe; base += TKF_ROWS) {
+  for (int64_t base = xb; base < xe; base += ROWS) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (base + TKF_ROWS < xe) issue_stage(buf ^ 1, base + TKF_ROWS);
-    f32x16 acc[2];
+    if (base + ROWS < xe) issue_stage(buf ^ 1, base + ROWS);
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       // accumulator input: |x|^2 of the 16 rows this lane owns: (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 v = *reinterpret_cast<const float4*>(&tn_s[buf * TKF_ROWS + t * 32 + 8 * q4 + 4 * half]);
+        const float4 v = *reinterpret_cast<const float4*>(&tn_s[buf * ROWS + t * 32 + 8 * q4 + 4 * half]);
         acc[t][4 * q4 + 0] = v.x; acc[t][4 * q4 + 1] = v.y; acc[t][4 * q4 + 2] = v.z; acc[t][4 * q4 + 3] = v.w;
       }
     }
-    const char* st = lds + buf * STAGE_BYTES + col * PITCH_B + half * 16;
+    const char* st = lds + buf * STAGE_PITCH + col * PITCH_B + half * 16;
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const f16x8 ah = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64);
         const f16x8 al = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64 + 32);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc[t], 0, 0, 0);
+        if (TERMS == 3) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc[t], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[t][r];
@@ -1335,14 +1344,15 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
   }
 }
 
-template <int DCH>
+template <int DCH, int TERMS, int ROWS>
 static int launch_topk_f16(dim3 grid, hipStream_t s, const _Float16* qimg, int64_t nq, const _Float16* ximg,
                            int64_t nx, const double* xn, int nsplit, int* cand_i, float* tau) {
-  constexpr int LDS_BYTES = 2 * TKF_ROWS * (DCH * 64 + 16) + 2 * TKF_ROWS * (int)sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_f16<DCH>),
+  constexpr int LDS_BYTES = 2 * ((ROWS * (DCH * 64 + 16) + 1023) / 1024 * 1024) + 2 * ROWS * (int)sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_f16<DCH, TERMS, ROWS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   CS_REQUIRE(attr == hipSuccess, CS_ERR_HIP, "cs_l2_topk: cannot reserve %d bytes of LDS", LDS_BYTES);
-  hipLaunchKernelGGL(k_topk_f16<DCH>, grid, dim3(512), LDS_BYTES, s, qimg, nq, ximg, nx, xn, nsplit, cand_i, tau);
+  hipLaunchKernelGGL((k_topk_f16<DCH, TERMS, ROWS>), grid, dim3(512), LDS_BYTES, s, qimg, nq, ximg, nx, xn, nsplit,
+                     cand_i, tau);
   return CS_OK;
 }
 
@@ -1350,14 +1360,17 @@ static int launch_topk_f16(dim3 grid, hipStream_t s, const _Float16* qimg, int64
 // flagged queries (compact list + count) go through the f64 path.
 __global__ void k_tkf_verify(const unsigned long long* __restrict__ carry_d, int k, int64_t nq,
                              const float* __restrict__ tau, int nlane, const double* __restrict__ qn,
-                             const unsigned* __restrict__ xmax_bits, int d, int* __restrict__ flagged,
-                             int* __restrict__ n_flagged) {
+                             const unsigned* __restrict__ xmax_bits, int d, int terms,
+                             int* __restrict__ flagged, int* __restrict__ n_flagged) {
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (q >= nq) return;
   float t = INFINITY;
   for (int j = 0; j < nlane; ++j) t = fminf(t, tau[q * nlane + j]);
   const double dk = __longlong_as_double((long long)carry_d[q * k + k - 1]);   // exact k-th squared distance
-  const double eps = (double)(3 * d + 4) * 2.384185791015625e-07 * (qn[q] + (double)__uint_as_float(*xmax_bits));
+  const double xm = (double)__uint_as_float(*xmax_bits);   // max |x|^2 (rounded up)
+  double eps = (double)(3 * d + 4) * 2.384185791015625e-07 * (qn[q] + xm)                    // relative: 2^-22
+               + 5.9604644775390625e-08 * sqrt((double)d) * (2.0 * sqrt(qn[q]) + sqrt(xm));  // absolute: 2^-24
+  if (terms < 3) eps += 1.001 * 9.765625e-04 * sqrt(qn[q]) * sqrt(xm);                      // dropped x_hi v_lo: 2^-10 |q||x|
   // f16 range: |x| and |-2 q| below 2e4 keep every hi part (and every product sum) finite; anything larger
   // (or not finite) cannot be trusted and takes the f64 path
   const bool in_range = __uint_as_float(*xmax_bits) < 4.0e8f && qn[q] < 1.0e8;
@@ -1820,7 +1833,7 @@ static int topk_f64_shortlist(const float* d_q, int64_t nq, const float* d_x, in
 // {queries through the f16 shortlist, of those recomputed by the f64 path}
 static std::atomic<unsigned long long> g_topk_stats[2];
 
-// f16 matrix-core shortlist (d = 64 / 128 / 256, k <= 10), canonical re-score, verification, f64 path for
+// f16 matrix-core shortlist (d = 64 / 128 / 256 / 512, k <= 10), canonical re-score, verification, f64 path for
 // the queries that fail it.  Waits for the stream once (the number of such queries).
 static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
                               int64_t* d_idx, double* d_dist, hipStream_t s) {
@@ -1853,14 +1866,16 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(n_pad * dch, 256)), dim3(256), 0, s, d_x, nx, n_pad,
                      d, 1.0f, ximg.p, pitch_h);
   const dim3 grid((unsigned)qtiles, (unsigned)nsplit);
-  int rc = dch == 16  ? launch_topk_f16<16>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
-           : dch == 8 ? launch_topk_f16<8>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
-                      : launch_topk_f16<4>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p);
+  const int terms = dch == 32 ? 2 : 3;
+  int rc = dch == 32   ? launch_topk_f16<32, 2, 32>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
+           : dch == 16 ? launch_topk_f16<16, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
+           : dch == 8  ? launch_topk_f16<8, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
+                       : launch_topk_f16<4, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p);
   if (rc) return rc;
   hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand, k,
                      cd.p, ci.p);
   hipLaunchKernelGGL(k_tkf_verify, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, cd.p, k, nq, tau.p,
-                     nlane, qn.p, xmax.p, d, flagged.p, n_flagged);
+                     nlane, qn.p, xmax.p, d, terms, flagged.p, n_flagged);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p, ci.p,
                      nq * k, d_idx, d_dist);
   CS_LAUNCH_CHECK();
@@ -1908,7 +1923,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   // f16 where the shape allows, else f64, for nq * nx >= 2^24.
   const char* force = getenv("CS_TOPK_MFMA");
   const bool big = (double)nq * (double)nx >= 16777216.0;
-  const bool f16_shape = (d == 64 || d == 128 || d == 256) && k <= TKF_KK - 2 && nx >= TKF_ROWS;
+  const bool f16_shape = (d == 64 || d == 128 || d == 256 || d == 512) && k <= TKF_KK - 2 && nx >= TKF_ROWS;
   const bool want16 = force ? (force[0] == '1' && force[1] == '6') : big;
   const bool want64 = force ? (force[0] == '1' || force[0] == '6') : big;
   if (want16 && f16_shape) return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);

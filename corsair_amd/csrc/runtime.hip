@@ -22,9 +22,18 @@ void set_error(const char* fmt, ...) {
 // ---- pool -------------------------------------------------------------------------------
 // Freed blocks are cached PER HOST THREAD: a thread drives one stream, so a block it frees while its
 // kernels are still queued is handed out again only to later work of the same stream (stream order
-// makes that safe without a synchronisation).  Another thread, on another stream, never receives it.
+// makes that safe without a synchronisation).  Another thread, on another stream, never receives it:
+// every live block remembers the thread that allocated it, and a block freed by a DIFFERENT thread
+// (a map handle dropped by Python's garbage collector on a helper or worker thread, say) does not enter
+// that thread's cache -- it goes back to the driver with hipFree, which waits for the device, so work the
+// owner's stream still has in flight on the block finishes first.  Rare and slow by design.
 static std::mutex g_pool_mu;
-static std::map<void*, size_t> g_live;                // block -> size class (all threads)
+struct LiveBlock {
+  size_t cls;           // size class
+  const void* owner;    // identity of the allocating thread (address of its thread-local cache)
+};
+static std::map<void*, LiveBlock> g_live;             // block -> size class + owner (all threads)
+static unsigned long long g_foreign_frees = 0;        // blocks freed by a thread other than their owner
 struct ThreadCache {
   std::map<size_t, std::vector<void*>> free_;          // size class -> blocks
   ~ThreadCache() {
@@ -84,21 +93,39 @@ void* pool_alloc(size_t bytes) {
     }
   }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_live[p] = c;
+  g_live[p] = LiveBlock{c, &t_cache};
   return p;
 }
 
 void pool_free(void* p) {
   if (!p) return;
-  size_t c;
+  LiveBlock b;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    c = it->second;
+    b = it->second;
     g_live.erase(it);
+    if (b.owner != &t_cache) ++g_foreign_frees;
   }
-  t_cache.free_[c].push_back(p);
+  if (b.owner != &t_cache) {
+    // not ours: the owner's stream may still be reading it and this thread's stream is not ordered
+    // against that stream.  hipFree synchronises the device before it releases the memory.
+    (void)hipFree(p);
+    return;
+  }
+  // ours: later work of this thread is enqueued behind whatever still uses the block (same stream, or a
+  // stream this thread drained when it switched: pool_use_stream)
+  t_cache.free_[b.cls].push_back(p);
+}
+
+void pool_stats(unsigned long long out[3]) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  out[0] = (unsigned long long)g_live.size();
+  out[1] = g_foreign_frees;
+  unsigned long long cached = 0;
+  for (const auto& kv : t_cache.free_) cached += (unsigned long long)kv.first * kv.second.size();
+  out[2] = cached;
 }
 
 // ---- small device -> host downloads ----------------------------------------------------------
@@ -261,6 +288,12 @@ int cs_device_count(void) {
 }
 
 void cs_pool_trim(void) { cs::trim_thread_cache(); }
+
+void cs_pool_stats(uint64_t out[3]) {
+  unsigned long long v[3];
+  cs::pool_stats(v);
+  for (int i = 0; i < 3; ++i) out[i] = v[i];
+}
 
 void cs_prof_enable(int on) { cs::g_prof_on = on; }
 

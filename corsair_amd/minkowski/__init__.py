@@ -324,6 +324,11 @@ class _Utils:
         g = np.floor(c).astype(np.int64)
         _, first, inverse = np.unique(g, axis=0, return_index=True, return_inverse=True)
         order = np.sort(first)
+        # np.unique numbers the voxels lexicographically; the kept points are in input order: renumber the
+        # inverse map so that  g[order][inverse] == g  (voxel of point i = row inverse[i] of the output)
+        rank = np.empty(len(first), dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(len(first))
+        inverse = rank[np.asarray(inverse).reshape(-1)]
         if return_maps_only:
             return (order, inverse) if return_inverse else order
         out = [g[order].astype(np.int32)]
@@ -331,6 +336,8 @@ class _Utils:
             out.append(np.asarray(features)[order])
         if return_index:
             out.append(order)
+        if return_inverse:
+            out.append(inverse)
         return out[0] if len(out) == 1 else tuple(out)
 
     @staticmethod

@@ -7,8 +7,11 @@ import os
 import torch
 
 
-def load_checkpoint(model, embedding, optimizer, scheduler, path):
-    checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+def load_checkpoint(model, embedding, optimizer, scheduler, path, trust_pickle=False):
+    """utils/ckpts.py:21-40.  Optimizer / scheduler state of a training checkpoint may hold arbitrary
+    pickled objects: `trust_pickle=True` opts in to full unpickling for files from a trusted source;
+    the default loads tensors and plain containers only (released checkpoints are third-party files)."""
+    checkpoint = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
     model.load_state_dict(checkpoint["state_dict"])
     embedding.load_state_dict(checkpoint["embedding_state_dict"])
     optimizer.load_state_dict(checkpoint["optimizer"])
@@ -31,5 +34,5 @@ def save_checkpoint(model, embedding, optimizer, scheduler, epoch, save_dir, sav
 def load_state_dicts(path):
     """(state_dict, embedding_state_dict or None) of a checkpoint file as host tensors: what
     ``corsair_amd.engine.ResUNetEngine`` consumes (evaluation.py:195-201 loads the same two entries)."""
-    checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+    checkpoint = torch.load(path, map_location="cpu", weights_only=True)   # two dicts of tensors: no pickle code
     return checkpoint["state_dict"], checkpoint.get("embedding_state_dict")

@@ -268,6 +268,11 @@ int cs_prof_get_units(const char* name, double* units);
 /* Return the calling thread's cached scratch memory to the HIP runtime.  Scratch is cached per host
  * thread (one stream per thread), so the library may be driven from several threads at once. */
 void cs_pool_trim(void);
+/* out = {live scratch/handle blocks, blocks freed by a thread other than the one that allocated them,
+ * bytes cached by the calling thread}.  A handle (cs_coordmap_free / cs_kernelmap_free) may be dropped on
+ * any thread: a foreign block is released with hipFree (device-synchronising), never recycled into the
+ * freeing thread's stream-ordered cache. */
+void cs_pool_stats(uint64_t out[3]);
 
 #ifdef __cplusplus
 }

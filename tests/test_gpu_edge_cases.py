@@ -95,3 +95,54 @@ def test_ragged_batch_forward_row_order(gpu):
     out1, feat1, maps1 = eng.forward(torch.from_numpy(solo).to(gpu), torch.ones((len(solo), 1), device=gpu))
     g1 = eng.embed(feat1, maps1, 1)
     assert torch.equal(out[len(coords):], out1) and torch.equal(g[3], g1[0])
+
+
+def test_handles_dropped_on_another_thread_do_not_enter_its_cache(gpu):
+    """coordinate / kernel maps are freed from Python __del__, which runs on whichever
+    thread drops the last reference.  Scratch is cached per thread in stream order, so a block freed
+    by a foreign thread must not be recycled there (its owner's stream may still read it): the pool
+    releases it with hipFree instead.  Maps are built (and used) on a worker thread with its own
+    stream, dropped on the main thread; the results stay right and the pool reports the foreign frees."""
+    import ctypes
+    import threading
+
+    from corsair_amd import _lib, backend as B, engine
+    from tests.helpers import make_batch
+
+    lib = _lib.load()
+    stats = (ctypes.c_uint64 * 3)()
+    lib.cs_pool_stats(stats)
+    foreign0 = int(stats[1])
+    coords, feats, _, _ = make_batch([0, 1], n_points=3000)
+    grid = torch.from_numpy(coords).to(gpu)
+    x = torch.from_numpy(feats).to(gpu)
+    w = torch.full((27, 1, 32), 0.25, device=gpu)
+    box = {}
+
+    def worker():
+        torch.cuda.set_device(gpu)
+        st = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(st):
+            m = engine.BatchMaps(grid)
+            box["y"] = B.conv_fwd(m.s1, x, w)
+            box["maps"] = m            # the last reference leaves this thread alive
+            st.synchronize()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    want = B.conv_fwd(engine.BatchMaps(grid).s1, x, w)
+    assert torch.equal(box["y"], want)
+    live_before = None
+    lib.cs_pool_stats(stats)
+    live_before = int(stats[0])
+    del box["maps"]                    # __del__ -> cs_kernelmap_free / cs_coordmap_free on THIS thread
+    import gc
+
+    gc.collect()
+    lib.cs_pool_stats(stats)
+    assert int(stats[1]) > foreign0, "blocks freed by a foreign thread were not detected"
+    assert int(stats[0]) < live_before
+    # this thread's cache did not receive them: a fresh build here still computes the right thing
+    again = B.conv_fwd(engine.BatchMaps(grid).s1, x, w)
+    assert torch.equal(again, want)

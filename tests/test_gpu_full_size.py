@@ -37,6 +37,42 @@ def test_forward_batch32_is_deterministic_and_sample_independent(gpu):
         assert torch.equal(g[0], glob1[j]), j
 
 
+def test_forward_batch64_stress_shape_is_deterministic_and_sample_independent(gpu):
+    """BASELINE.json configs[4]: batch-64 forward on 15 000-point clouds at 2 cm voxels (~9 k voxels per
+    cloud, ~0.6 M rows per batch: the kernel-map LDS path, its global-table fallback for the big samples
+    and the large-tile convolution kernels at a size the oracle cannot reach)."""
+    from corsair_amd import backend as B, engine, synth
+
+    ids = list(range(300, 364))
+    clouds = [synth.make_cloud(c, 15000) for c in ids]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).tolist()
+    xyz = torch.from_numpy(np.concatenate(clouds)).to(gpu)
+    keep, grid, voff = B.voxelize(xyz, off, 0.02)
+    n = grid.shape[0]
+    assert 64 * 6000 < n < 64 * 13000                       # SURVEY 8d: 8-9 k voxels per cloud at 2 cm
+    sd, emb = synth.make_state_dicts(31)
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    feats = torch.ones((n, 1), dtype=torch.float32, device=gpu)
+
+    def run(g, f, nb):
+        out, feat8, maps = eng.forward(g, f)
+        return out, eng.embed(feat8, maps, nb), maps
+
+    out1, glob1, maps = run(grid, feats, 64)
+    out2, glob2, _ = run(grid, feats, 64)
+    assert torch.equal(out1, out2) and torch.equal(glob1, glob2)
+    assert out1.shape == (n, 16) and glob1.shape == (64, 256) and bool(torch.isfinite(out1).all())
+    assert torch.allclose(out1.norm(dim=1), torch.ones_like(out1[:, 0]), atol=1e-5)
+    pairs = maps.total_pairs()
+    assert 6.0 < pairs["s1"] / n < 16.0 and pairs["s1_s2"] == pairs["s2_s1_T"]
+    for j in (0, 29, 63):                                    # a cloud alone gives the same rows and descriptor
+        g1 = grid[voff[j]:voff[j + 1]].clone()
+        g1[:, 0] = 0
+        o, g, _ = run(g1.contiguous(), feats[: g1.shape[0]], 1)
+        assert torch.equal(o, out1[voff[j]:voff[j + 1]]), j
+        assert torch.equal(g[0], glob1[j]), j
+
+
 def test_retrieval_c2_properties(gpu):
     from corsair_amd import backend as B, synth
 

@@ -380,7 +380,8 @@ def _topk_stats(reset=False):
 
 
 @pytest.mark.parametrize("nq,nx,d,k", [(37, 5000, 256, 10), (300, 9000, 128, 1), (130, 20000, 64, 10),
-                                       (5, 64, 256, 3), (700, 777, 256, 10)])
+                                       (5, 64, 256, 3), (700, 777, 256, 10), (290, 6000, 512, 10),
+                                       (33, 97, 512, 4)])
 def test_l2_topk_f16_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, nq, nx, d, k):
     """The f16 matrix-core shortlist + exact re-score + verification path returns exactly the ids and
     distances of the canonical chain; exact ties at the k-th neighbour (duplicated catalog rows) make the
@@ -436,6 +437,28 @@ def test_l2_topk_f16_falls_back_on_ties_and_scales(gpu, oracle_native, monkeypat
     took, fell_back = _topk_stats()
     assert took == 50 and fell_back == 0
     assert np.array_equal(idx.cpu().numpy(), np.argsort(oracle_native.dist2_matrix(q, base), axis=1, kind="stable")[:, :5])
+
+
+@pytest.mark.parametrize("d", [256, 512])
+def test_l2_topk_f16_tiny_norms_take_the_absolute_error_term(gpu, oracle_native, monkeypatch, d):
+    """descriptors scaled by 1e-4 put the hi / lo halves of the f16 split into the subnormal
+    range, where the split error is absolute (2^-25 per element), not relative.  With the absolute term in
+    the verification bound the result is still exactly the canonical chain's -- through the shortlist or,
+    where the bound no longer separates, through the f64 recomputation."""
+    from corsair_amd import backend as B, synth
+
+    monkeypatch.setenv("CS_TOPK_MFMA", "16")
+    for scale_q, scale_x in ((1e-4, 1e-4), (1.0, 1e-4), (3e-3, 2.0)):
+        q = (synth.make_descriptors(64, d, seed=41) * np.float32(scale_q)).astype(np.float32)
+        x = (synth.make_descriptors(4096, d, seed=42) * np.float32(scale_x)).astype(np.float32)
+        _topk_stats(reset=True)
+        idx, dist = B.l2_topk(torch.from_numpy(q).to(gpu), torch.from_numpy(x).to(gpu), 10, True)
+        took, _ = _topk_stats()
+        assert took == 64
+        d2 = oracle_native.dist2_matrix(q, x)
+        want = np.argsort(d2, axis=1, kind="stable")[:, :10]
+        assert np.array_equal(idx.cpu().numpy(), want), (scale_q, scale_x)
+        assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
 
 
 def test_l2_topk_large_matches_exact_slab_path(gpu, monkeypatch):

@@ -101,6 +101,19 @@ def _coords(seed, n=500, span=8, batch=2):
     return np.concatenate(out).astype(np.int32)
 
 
+def test_shim_sparse_quantize_inverse_map_pairs_with_the_kept_rows():
+    """ME.utils.sparse_quantize(return_index=True, return_inverse=True): coords[index][inverse] == coords
+    (VERDICT r1 hygiene: the inverse used to follow np.unique's lexicographic numbering)."""
+    import corsair_amd.minkowski as ME
+
+    rng = np.random.default_rng(1)
+    g = rng.integers(-4, 4, (3000, 3))
+    idx, inv = ME.utils.sparse_quantize(g, return_index=True, return_inverse=True, return_maps_only=True)
+    assert (np.diff(idx) > 0).all() and np.array_equal(g[idx][inv], g)
+    q, idx2, inv2 = ME.utils.sparse_quantize(g, return_index=True, return_inverse=True)
+    assert np.array_equal(idx2, idx) and np.array_equal(inv2, inv) and np.array_equal(q, g[idx])
+
+
 def test_sparse_quantize_keeps_first_point_per_voxel():
     from oracle import sparse
 
