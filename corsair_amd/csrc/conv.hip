@@ -199,6 +199,230 @@ __global__ __launch_bounds__(256) void k_conv_mfma(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_conv_lacc: sparse convolution with accumulators in LDS and per-offset ROW COMPACTION (round 2).
+//
+// k_conv_mfma keeps a tile's accumulators in registers, so every row of a tile pays the MFMA time of
+// every offset the TILE uses: x1.6 - 2.2 of the useful work on real occupancy (a voxel has ~10 of its 27
+// neighbours).  Here a WAVE owns 64 output rows x TN channels whose accumulators live in its private
+// slice of LDS; for every offset k the rows that have neighbour k are compacted (ballot + mbcnt: lane =
+// row) and only they go through the matrix pipe, 32 at a time:
+//     C  <- LDS accumulator rows of the group      (v_mfma_f32_32x32x2_f32 accumulator INPUT)
+//     C  <- the fma chain over the Cin channels    (same chain, same order: bit-identical results)
+//     LDS <- C
+// Executed / useful MFMA work on the bench clouds: 1.2 - 1.6 (mask-sorted rows), against 1.6 - 2.6.
+// No workgroup barrier anywhere: the four waves of a workgroup are independent (LDS is wave-private,
+// LDS operations of one wave execute in order), so a wave never waits for its neighbours' gathers.
+// Operands come straight from global memory / L2, no LDS staging:
+//   * A (gathered input rows): lane (half h, row j) loads channels [16 h, 16 h + 16) of its row with four
+//     16-byte loads; MFMA i of the 32-channel chunk needs channel 2 i + h in lane (h, j), which is what ONE
+//     v_permlane32_swap per register pair produces: swap(X[2m], X[2m+1]) leaves (ch 2m | ch 2m+1) in the
+//     first register = operand of MFMA m, and (ch 16+2m | ch 17+2m) in the second = operand of MFMA 8+m.
+//   * B (weights W[k][ci][co], reference layout): lane (h, c) reads W[k][ci0 + 2 i + h][n0 + 32 t + c]:
+//     two coalesced 128-byte rows per MFMA, L2-resident (a layer's weights are 27 Cin Cout 4 B <= 7 MB).
+// The next chunk's A and B registers are loaded while the current chunk's MFMAs run.
+// ------------------------------------------------------------------------------------------------
+#ifndef CONV_DBG
+#define CONV_DBG 0   // timing experiments only (tools/conv_dbg.sh): 1 no A loads, 2 no B loads, 4 no MFMAs
+#endif
+template <int NT>
+__global__ __launch_bounds__(256) void k_conv_lacc(
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist, int kvol, int64_t n_out,
+    const float* __restrict__ in, int ld_in, int cin, const float* __restrict__ w, int cout,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out, int ld_out) {
+  constexpr int TN = 32 * NT;
+  constexpr int R = 64;                    // output rows per wave (lane = row)
+  constexpr int DUMMY = R;                 // accumulator row of the padded slots of a group
+  // dynamic LDS: 4 waves x ((R + 1) x TN floats + 2 lists x R uint16) = 66 KiB for TN = 64
+  extern __shared__ __attribute__((aligned(16))) char lacc_lds[];
+  constexpr int ROWB = TN * 4;             // bytes per accumulator row
+  constexpr int WAVE_BYTES = (R + 1) * ROWB + 2 * R * 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c = lane & 31;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  if (row0 >= n_out) return;               // whole wave; no barriers below
+  const int n0 = blockIdx.y * TN;
+  char* ACCB = lacc_lds + wave * WAVE_BYTES;                              // accumulators, byte-addressed
+  unsigned short* LIST = reinterpret_cast<unsigned short*>(ACCB + (R + 1) * ROWB);   // [2][R] byte offsets of rows
+
+  // this lane's output row, its 27 neighbour rows (registers) and their presence mask
+  int o = -1;
+  if (row0 + lane < n_out) o = rowlist ? rowlist[row0 + lane] : (int)(row0 + lane);
+  int nb[27];
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    nb[k] = (o >= 0 && k < kvol) ? nbr[(int64_t)o * kvol + k] : -1;
+    mask |= (nb[k] >= 0 ? 1u : 0u) << k;
+  }
+  {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < TN / 4; ++q) *reinterpret_cast<float4*>(ACCB + lane * ROWB + 16 * q) = z;
+    if (lane < TN / 4) *reinterpret_cast<float4*>(ACCB + DUMMY * ROWB + 16 * lane) = z;
+  }
+  const int cchunks = cin >> 5;
+
+  // first offset >= from that some row of this wave has (wave-uniform), 27 = none
+  auto next_k = [&](int from) {
+    int kk = from;
+    while (kk < kvol && __ballot((mask >> kk) & 1u) == 0ULL) ++kk;
+    return kk < kvol ? kk : 27;
+  };
+  // compacted list of the rows that have offset kk, as byte offsets of their accumulator rows, padded with the
+  // DUMMY row to whole groups of 32 -> LIST[buf][0 .. ceil32(count)); nbk = this lane's neighbour for kk
+  auto build_list = [&](int kk, int buf, int& nbk) {
+    const bool has = (mask >> kk) & 1u;
+    const unsigned long long bal = __ballot(has);
+    const int cnt = (int)__popcll(bal);
+    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    if (has) LIST[buf * R + pos] = (unsigned short)(lane * ROWB);
+    if (lane >= cnt && lane < ((cnt + 31) & ~31)) LIST[buf * R + lane] = (unsigned short)(DUMMY * ROWB);
+    nbk = nb[0];
+#pragma unroll
+    for (int q = 1; q < 27; ++q) nbk = kk == q ? nb[q] : nbk;   // uniform selects, once per offset
+    __builtin_amdgcn_wave_barrier();       // (compiler ordering only: same-wave LDS ops execute in order)
+    return cnt;
+  };
+  // input row this lane gathers for group (g0 of the list in buf): compacted slot g0 + c (both halves: the
+  // same row).  Padded slots read some valid row: their products land in the DUMMY accumulator row and are
+  // never used, so the loads need no predicate (an exec-masked load puts a branch and a register merge into
+  // the pipeline).
+  auto prep = [&](int nbk, int g0, int buf) -> const float* {
+    const int rho = (int)LIST[buf * R + g0 + c] / ROWB;   // owner lane of the row (DUMMY -> 64 -> lane 0)
+    const int src = max(__shfl(nbk, rho), 0);
+    return in + (int64_t)src * ld_in + 16 * h;
+  };
+  auto load_a = [&](const float* p4, float4 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dst[q] = (CONV_DBG & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p4 + 4 * q);
+  };
+  // B operand: uniform base (SGPRs) + one per-lane 32-bit offset shared by every load
+  const int loff = h * cout + c;
+  auto wslab = [&](int kk, int cc) { return w + ((int64_t)kk * cin + cc * 32) * cout + n0; };   // wave-uniform
+
+  int k = next_k(0);
+  if (k < 27) {
+    int buf = 0, g0 = 0, nbk = 0, nnbk = 0;
+    int mk = build_list(k, buf, nbk);
+    const float* arow = prep(nbk, g0, buf);
+    float4 x[4];
+    float b[16][NT];
+    load_a(arow, x);
+    {
+      const float* wu = wslab(k, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[i][t] = (CONV_DBG & 2) ? 1.0f : (wu + (int64_t)(2 * i) * cout + 32 * t)[loff];
+    }
+    bool more = true;
+    while (more) {
+      // LDS byte addresses of the accumulator rows of this lane's 16 result registers: slots
+      // (i & 3) + 8 (i >> 2) + 4 h of the group, column c
+      unsigned addr[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 pr = *reinterpret_cast<const uint2*>(&LIST[buf * R + g0 + 8 * q + 4 * h]);
+        addr[4 * q + 0] = (pr.x & 0xffffu) + 4 * c;
+        addr[4 * q + 1] = (pr.x >> 16) + 4 * c;
+        addr[4 * q + 2] = (pr.y & 0xffffu) + 4 * c;
+        addr[4 * q + 3] = (pr.y >> 16) + 4 * c;
+      }
+      f32x16 acc[NT];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][i] = *reinterpret_cast<const float*>(ACCB + addr[i] + 128 * t);
+      // the group after this one: its first operands are requested under this group's last chunk
+      int nk = k, ng0 = g0 + 32, nmk = mk, nbuf = buf;
+      nnbk = nbk;
+      if (ng0 >= mk) {
+        nk = next_k(k + 1);
+        ng0 = 0;
+        nbuf = buf ^ 1;
+        if (nk < 27) nmk = build_list(nk, nbuf, nnbk);
+      }
+      more = nk < 27;
+      const int kn = more ? nk : k;         // (after the last group: harmless re-reads of valid addresses)
+      const float* narow = more ? prep(nnbk, ng0, nbuf) : arow;
+      for (int cc = 0; cc < cchunks; ++cc) {
+        float a[16];
+        {
+          const float X[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                               x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[2 * m]), __float_as_uint(X[2 * m + 1]),
+                                                             false, false);
+            a[m] = __uint_as_float(sw[0]);
+            a[8 + m] = __uint_as_float(sw[1]);
+          }
+        }
+        // operands of the chunk after this one (next chunk of the group, or first chunk of the next group):
+        // one branch-free set of loads; every B register is reloaded right behind the MFMA that consumed it
+        const bool last = cc + 1 == cchunks;
+        const float* pa = last ? narow : arow + (cc + 1) * 32;
+        const float* wu = last ? wslab(kn, 0) : wslab(k, cc + 1);
+        load_a(pa, x);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (CONV_DBG & 4)
+              acc[t][i] += a[i] * b[i][t];
+            else
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][t], acc[t], 0, 0, 0);
+            b[i][t] = (CONV_DBG & 2) ? 1.0f : (wu + (int64_t)(2 * i) * cout + 32 * t)[loff];
+          }
+        // keep that order: one MFMA, then the reload of the register it consumed (hipcc otherwise sinks all the
+        // loads below the MFMA block, where the next chunk waits a full L2 latency for them)
+#pragma unroll
+        for (int j = 0; j < 16 * NT; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<float*>(ACCB + addr[i] + 128 * t) = acc[t][i];
+      __builtin_amdgcn_wave_barrier();
+      k = nk;
+      g0 = ng0;
+      mk = nmk;
+      buf = nbuf;
+      nbk = nnbk;
+      arow = narow;
+    }
+  }
+
+  // epilogue: row-major LDS -> coalesced global rows (64 / TN rows per pass)
+  {
+    constexpr int RPP = 64 / TN;            // rows per pass
+    const int col = n0 + (lane & (TN - 1));
+    const int sub = lane / TN;
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+    for (int r0 = 0; r0 < R; r0 += RPP) {
+      const int r = r0 + sub;
+      const int o_r = __shfl(o, r);
+      if (o_r < 0) continue;
+      float v = *reinterpret_cast<const float*>(ACCB + r * ROWB + 4 * (lane & (TN - 1)));
+      if (scale)
+        v = __fmaf_rn(v, sc, sh);
+      else if (shift)
+        v = v + sh;
+      if (residual) v = v + residual[(int64_t)o_r * ld_res + col];
+      if (relu) v = fmaxf(v, 0.0f);
+      out[(int64_t)o_r * ld_out + col] = v;
+    }
+  }
+}
+
 // Generic VALU path (any cin / cout / alignment; used for cin = 1, the 1 -> 32 stem conv).
 // One thread per (out row, out channel); same canonical fma order.
 __global__ void k_conv_generic(const int32_t* __restrict__ nbr, int kvol, int64_t n_out,
@@ -400,7 +624,31 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   ProfScope prof("conv", s, flop);
   const bool mfma_ok = (cin % 32 == 0) && (cout % 4 == 0) && (ld_in % 4 == 0) &&
                        aligned16(d_in) && aligned16(d_w);
-  if (mfma_ok) {
+  // CS_CONV_LACC=1: the LDS-accumulator kernel with per-offset row compaction (k_conv_lacc).  Bit-identical
+  // results, 1.2 - 1.6x fewer MFMAs, but measured SLOWER than the register-accumulator kernel below on the
+  // bench shapes (DESIGN.md "what was tried on the sparse convolution"): operands fetched per 32-row group
+  // straight from L2 cost more than the LDS-staged 64-row tiles save.  Off by default, kept under test.
+  const bool lacc_on = getenv("CS_CONV_LACC") && getenv("CS_CONV_LACC")[0] == '1';
+  if (mfma_ok && lacc_on && nbr && kvol > 1 && cout % 32 == 0) {
+    const unsigned wgs = (unsigned)ceil_div(ceil_div(n_out, 64), 4);
+    constexpr int LDS2 = 4 * (65 * 64 * 4 + 256), LDS1 = 4 * (65 * 32 * 4 + 256);
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_lacc<2>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+    CS_REQUIRE(attr2 == hipSuccess, CS_ERR_HIP, "cs_conv_fwd: cannot reserve %d bytes of LDS", LDS2);
+    CS_REQUIRE(kvol <= 27, CS_ERR_UNSUPPORTED, "cs_conv_fwd: kernel volume %d", kvol);
+    // 64-column tiles halve the gather traffic, 32-column tiles double the number of waves: the wide form only
+    // when it still gives every SIMD several waves (CS_CONV_NT=1/2 forces one, for experiments)
+    const int force_nt = getenv("CS_CONV_NT") ? atoi(getenv("CS_CONV_NT")) : 0;
+    const bool wide = force_nt ? force_nt == 2 : (int64_t)ceil_div(n_out, 64) * (cout / 64) >= 4096;
+    if (cout % 64 == 0 && wide)
+      hipLaunchKernelGGL((k_conv_lacc<2>), dim3(wgs, (unsigned)(cout / 64)), dim3(256), LDS2, s, nbr, rowlist, kvol,
+                         n_out, d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out,
+                         ld_out);
+    else
+      hipLaunchKernelGGL((k_conv_lacc<1>), dim3(wgs, (unsigned)(cout / 32)), dim3(256), LDS1, s, nbr, rowlist, kvol,
+                         n_out, d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out,
+                         ld_out);
+  } else if (mfma_ok) {
     // 64 x 128 tiles unless that leaves half of the 256 CUs without a workgroup (coarsest level)
     if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) > 128) {
       dim3 grid((unsigned)ceil_div(n_out, 64), (unsigned)(cout / 128));

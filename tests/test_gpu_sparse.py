@@ -66,6 +66,24 @@ def test_conv_bit_exact(gpu, oracle_native, cin, cout):
     assert got.shape == (n, cout) and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("nt", ["1", "2"])
+def test_conv_lds_accumulator_kernel_bit_exact(gpu, oracle_native, monkeypatch, nt):
+    """CS_CONV_LACC=1: the experimental k_conv_lacc (accumulators in LDS, rows compacted per offset, operands
+    straight from L2 through v_permlane32_swap) computes the same fma chains: whole network bit-exact."""
+    from corsair_amd import engine, synth
+    from oracle import resunet as oref
+
+    monkeypatch.setenv("CS_CONV_LACC", "1")
+    monkeypatch.setenv("CS_CONV_NT", nt)
+    coords, feats, _, _ = make_batch([5, 6, 7], n_points=5000)
+    sd, emb = synth.make_state_dicts(31)
+    eng = engine.ResUNetEngine(sd, emb, device=gpu)
+    out, feat, maps = eng.forward(torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu))
+    want_out, want_feat, _ = oref.resunet_forward(sd, coords, feats)
+    assert np.array_equal(out.cpu().numpy(), want_out)
+    assert np.array_equal(feat.cpu().numpy(), want_feat)
+
+
 def test_resunet_forward_bit_exact(gpu, oracle_native):
     from corsair_amd import engine, synth
     from oracle import resunet as oref
