@@ -324,6 +324,9 @@ class RegistrationWorkload:
                                    "note": "hypotheses whose f16 upper bound reached the best count and were "
                                            "recounted exactly / all hypotheses evaluated (whole run incl. warmup)"}
         out["shard_balance"] = self.balance
+        ps = (ctypes.c_uint64 * 3)()
+        _lib.load().cs_pool_stats(ps)
+        out["scratch_pool"] = {"live_blocks": int(ps[0]), "freed_by_a_foreign_thread": int(ps[1])}
 
     def cpu_baseline(self):
         """The CPU oracle (kind "port": the build's restatement of the reference CPU path, OpenMP over

@@ -1209,7 +1209,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const char* env_ck = getenv("CS_RANSAC_CHECK");
   const bool use_pf = !(env_pf && env_pf[0] == '0') && total > 0;
   const bool check = use_pf && env_ck && env_ck[0] == '1';
-  const int pf_from = 512;  // (256 was measured: no difference)
+  const int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : 512;  // (256 was measured in round 1: no difference)
   // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
   // [RansacProb x n_prob | n_surv int32 x n_prob (padded to 8 B) | n_active int32]
   const size_t st_probs = sizeof(RansacProb) * (size_t)n_prob;
