@@ -116,3 +116,38 @@ def test_shapenet_style_registration_eval(gpu):
                                          cfg.max_corr, 0, a0, a1, cfg.ransac_max_iter, cfg.ransac_confidence)
     assert np.array_equal(res[0]["T_est_ransac"], Tr) and np.array_equal(res[0]["T_est_sym"], Tb)
     assert res[0]["sym_success"] == ok
+
+
+def test_sharding_exchange_runs_on_rccl(gpu):
+    """The one exchange of the multi-GPU path (sharding.all_gather_counts / all_gather_embedded, bench.py's
+    reduce / gather helpers) through the REAL backend: torch.distributed "nccl" = RCCL, here with a
+    communicator of one rank on the one GPU of the test box (device tensors, int64 / f32 / f64 payloads,
+    padded ragged all-gathers).  The multi-rank logic itself is covered on gloo (tests/test_sharding_gloo.py);
+    this test catches what gloo cannot: a host tensor or an unsupported dtype handed to RCCL."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from corsair_amd import sharding
+    from corsair_amd.harness import EmbeddedSet
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        vox = sharding.all_gather_counts(dist, [0, 2, 1], [10, 30, 20], 3, 2)   # world 2 code path, 1 rank present
+        assert vox.tolist() == [10, 20, 30]
+        F = torch.arange(7 * 16, dtype=torch.float32, device=gpu).reshape(7, 16)
+        eset = EmbeddedSet(F, F[:, :3].contiguous(), [0, 3, 7], torch.ones((2, 256), device=gpu))
+        (got,) = sharding.all_gather_embedded(dist, eset, 1)
+        assert got.offsets == [0, 3, 7] and torch.equal(got.F, F) and torch.equal(got.desc, eset.desc)
+        t = torch.tensor([1.5, 2.5], device=gpu, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert t.tolist() == [1.5, 2.5]
+    finally:
+        dist.destroy_process_group()
