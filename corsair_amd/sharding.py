@@ -65,7 +65,7 @@ def all_gather_counts(dist, local_ids, local_counts, n_items, world):
     v = torch.zeros(n_items, dtype=torch.int64)
     if len(local_ids):
         v[torch.as_tensor(list(local_ids), dtype=torch.int64)] = torch.as_tensor(list(local_counts), dtype=torch.int64)
-    if world == 1 or dist is None:
+    if dist is None:
         return v.numpy()
     if dist.get_backend() == "nccl":
         v = v.cuda()
