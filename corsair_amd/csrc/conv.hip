@@ -650,7 +650,16 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
                          ld_out);
   } else if (mfma_ok) {
     // 64 x 128 tiles unless that leaves half of the 256 CUs without a workgroup (coarsest level)
-    if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) > 128) {
+    const bool short_tiles = !(getenv("CS_CONV_TILE") && getenv("CS_CONV_TILE")[0] == '0');
+    if (cout % 128 == 0 && short_tiles && ceil_div(n_out, 64) * (cout / 128) <= 512) {
+      // few rows (stride 4 / 8 levels of a 32-cloud batch): 32-row x 128-column tiles double the workgroups
+      // and narrow the union of offsets a tile has to walk (stride-4 layers 182 -> 165 us, conv4_tr 133 -> 100;
+      // CS_CONV_TILE=0: the 64-row tiles)
+      dim3 grid((unsigned)ceil_div(n_out, 32), (unsigned)(cout / 128));
+      hipLaunchKernelGGL((k_conv_mfma<1, 4, 1>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
+                         d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
+                         d_out, ld_out);
+    } else if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) > 128) {
       dim3 grid((unsigned)ceil_div(n_out, 64), (unsigned)(cout / 128));
       hipLaunchKernelGGL((k_conv_mfma<2, 2, 2>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_in, n_out,
                          d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu,
