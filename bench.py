@@ -136,7 +136,17 @@ class Ctx:
             import torch.distributed as dist
 
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
+                try:
+                    dist.init_process_group("nccl", device_id=self.dev)
+                    probe = torch.ones(1, device=self.dev)
+                    dist.all_reduce(probe)              # first collective: communicator really comes up
+                    torch.cuda.synchronize()
+                except Exception as e:                  # RCCL unusable on this node: the exchange is setup-only,
+                    sys.stderr.write("[bench] rank %d: RCCL init failed (%s); falling back to gloo\n" % (self.rank, e))
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                    self.backend = "gloo"
+                    dist.init_process_group("gloo")
             else:
                 dist.init_process_group(self.backend)
             self.dist = dist
