@@ -1840,7 +1840,13 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   const int dch = d / 16;
   const int pitch_h = dch * 32 + 8;  // halfs per catalog image row (16 B of padding)
   const int64_t qtiles = ceil_div(nq, TKF_QT);
-  int nsplit = (int)ceil_div(512, qtiles);
+  // catalog splits: one full round of workgroups.  d >= 256 leaves room for ONE workgroup per CU (2 x 65 KiB
+  // of LDS stages): 256 slots, filled without a partial second round (every split adds 24 candidates per
+  // query to the exact re-score: 10 240 x 10^6 x 256-d went from 30 to 22.5 ms with 6 splits instead of 13);
+  // the smaller images fit two per CU
+  const int wg_slots = getenv("CS_TOPK_SLOTS") ? atoi(getenv("CS_TOPK_SLOTS")) : (d >= 256 ? 256 : 512);
+  int nsplit = d >= 256 ? (int)(wg_slots / qtiles) : (int)ceil_div(wg_slots, qtiles);
+  if (nsplit < 2) nsplit = 2;   // (10^6 x 10^6: two half-catalog rounds measured 8 % faster than one full one)
   if (nsplit > 32) nsplit = 32;
   while (nsplit > 1 && nx / nsplit < 8 * TKF_ROWS) --nsplit;
   if (nsplit < 1) nsplit = 1;
