@@ -10,7 +10,7 @@
 //                       rigid fit (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f64
 //                       (Open3D keeps the Matrix4d; the f32 cast happens at the very end, where the
 //                       reference casts the result: utils/symmetry.py:274)
-//   k_ransac_prefilter  (from iteration 512 on) an UPPER bound of every hypothesis' inlier count on the
+//   k_ransac_prefilter  (from iteration 256 on) an UPPER bound of every hypothesis' inlier count on the
 //                       f16 matrix cores; hypotheses whose bound is below the carried best cannot
 //                       matter and get count 0.  ~0.02 % survive.  See the block comment above the
 //                       kernel and DESIGN.md ("RANSAC prefilter") for the bound.
@@ -20,7 +20,7 @@
 //                       registers), the pairs of a 256-row stage are converted to f64 once and read
 //                       from LDS as broadcasts; p = fma(r2,sz, fma(r1,sy, fma(r0,sx, t))), d = p - q,
 //                       |d|^2 = fma(dz,dz, fma(dy,dy, dx dx)) < max_corr^2 (the canonical chain, the
-//                       oracle's).  Used for all hypotheses of the first 512 iterations and (LIST) for
+//                       oracle's).  Used for all hypotheses of the first 256 iterations and (LIST) for
 //                       long survivor lists; k_ransac_count_few handles the usual handful of survivors
 //                       (same chain, count and fixed-point error in one pass).  These kernels see
 //                       ~0.1 % of the (hypothesis, pair) work; the f16 prefilter carries the rest.
@@ -1209,7 +1209,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const char* env_ck = getenv("CS_RANSAC_CHECK");
   const bool use_pf = !(env_pf && env_pf[0] == '0') && total > 0;
   const bool check = use_pf && env_ck && env_ck[0] == '1';
-  const int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : 512;  // (256 was measured in round 1: no difference)
+  // first chunk (all hypotheses counted exactly: there is no best count to prune against yet) and first
+  // prefiltered iteration.  Round 1 (f32 matrix-pipe exact kernel): 512 = 256, no difference; with the f64
+  // exact kernel of round 2 the unfiltered rounds are the expensive ones: 256 instead of 512 is +2.4 % queries/s
+  const int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 256;
+  const int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : first_chunk;
   // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
   // [RansacProb x n_prob | n_surv int32 x n_prob (padded to 8 B) | n_active int32]
   const size_t st_probs = sizeof(RansacProb) * (size_t)n_prob;
@@ -1310,7 +1314,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     bool pf = false, on_side = false;
   };
   auto chunk_of = [&](int it0) {
-    int b = it0 < 256 ? 256 : (it0 < bmax ? it0 : bmax);
+    int b = it0 < first_chunk ? first_chunk : (it0 < bmax ? it0 : bmax);
     return b > max_iter - it0 ? max_iter - it0 : b;
   };
   auto enqueue_front = [&](int it0, int par, hipStream_t st) -> Front {
