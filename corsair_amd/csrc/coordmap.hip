@@ -182,8 +182,7 @@ __global__ __launch_bounds__(256) void k_build_nbr_flagged(
 // handled by the global-table kernel (k_build_nbr, restricted to the flagged samples); batches that
 // are not grouped by sample use the global kernel for everything.
 // ------------------------------------------------------------------------------------------------
-constexpr int LDS_SLOTS = 24576;      // 4-B keys + 2-B local rows = 144 KB of the CU's 160 KB LDS
-constexpr int LDS_MAX_ROWS = 15360;   // load factor <= 0.625
+constexpr int LDS_SLOTS_MAX = 24576;  // 4-B keys + 2-B local rows = 144 KB of the CU's 160 KB LDS (load factor <= 0.625)
 constexpr uint32_t LDS_EMPTY = 0xffffffffu;
 
 // seg[b] = first row whose batch index is >= b (rows must be grouped by ascending batch index).
@@ -206,12 +205,18 @@ __global__ void k_segment_max(const int32_t* __restrict__ seg, int n_batch, int*
   if (b < n_batch) atomicMax(&flags[1], seg[b + 1] - seg[b]);
 }
 
-// grid: x = slice of the sample's output rows, y = sample.  block = 1024 threads.
-__global__ __launch_bounds__(1024) void k_build_nbr_lds(
+// grid: x = slice of the sample's output rows, y = sample.  block = NT threads.
+// SLOTS = table size: 24576 (144 KB, one workgroup per CU: the stride-1 maps of 15 k-voxel samples), 8192
+// (48 KB, three per CU) or 2048 (12 KB) for the coarser levels, picked on the host from the mean sample size;
+// a sample that does not fit its table is flagged and goes through the global table like any other overflow.
+template <int SLOTS, int NT>
+__global__ __launch_bounds__(NT) void k_build_nbr_lds(
     const int32_t* __restrict__ in_coords, const int32_t* __restrict__ in_seg,
     const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int step,
     int sign, int32_t* __restrict__ nbr, unsigned long long* __restrict__ pair_count,
     int* __restrict__ fallback) {
+  constexpr int LDS_SLOTS = SLOTS;
+  constexpr int LDS_MAX_ROWS = SLOTS / 8 * 5;   // load factor <= 0.625
   __shared__ uint32_t keys[LDS_SLOTS];
   __shared__ uint16_t vals[LDS_SLOTS];
   __shared__ int bmin[3], bmax[3];
@@ -227,13 +232,13 @@ __global__ __launch_bounds__(1024) void k_build_nbr_lds(
     bmin[tid] = 0x7fffffff;
     bmax[tid] = -0x7fffffff;
   }
-  for (int i = tid; i < LDS_SLOTS; i += 1024) keys[i] = LDS_EMPTY;
+  for (int i = tid; i < LDS_SLOTS; i += NT) keys[i] = LDS_EMPTY;
   __syncthreads();
   {
     // bounding box: per-thread, then per-wave (shuffles), then one LDS atomic per wave and axis
     // (one atomic per coordinate serialises ~27 k updates on six addresses: 85 us -> measured below)
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
-    for (int i = i0 + tid; i < i1; i += 1024) {
+    for (int i = i0 + tid; i < i1; i += NT) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const int v = in_coords[4 * i + 1 + a];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(1024) void k_build_nbr_lds(
     if (tid == 0) fallback[b] = 1;
     return;
   }
-  for (int i = i0 + tid; i < i1; i += 1024) {
+  for (int i = i0 + tid; i < i1; i += NT) {
     const uint32_t key = (uint32_t)((in_coords[4 * i + 1] - mx) / unit) |
                          ((uint32_t)((in_coords[4 * i + 2] - my) / unit) << 10) |
                          ((uint32_t)((in_coords[4 * i + 3] - mz) / unit) << 20);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_build_nbr_lds(
   __syncthreads();
   int found_total = 0;
   const int total = (s1 - s0) * 27;
-  for (int t = tid; t < total; t += 1024) {
+  for (int t = tid; t < total; t += NT) {
     const int o = s0 + t / 27;
     const int k = t - (t / 27) * 27;
     const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
@@ -748,9 +753,21 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
         if (slices > 8) slices = 8;
         e = hipMemsetAsync(fb.p, 0, sizeof(int) * (2 + nb), s);
         if (e == hipSuccess) {
-          hipLaunchKernelGGL(k_build_nbr_lds, dim3((unsigned)slices, (unsigned)nb), dim3(1024), 0, s,
-                             in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                             in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+          // table size from the mean in-sample size (2.5x headroom; larger samples take the flagged path)
+          const int64_t need = (in->n / (nb > 0 ? nb : 1)) * 5 / 2;
+          static const bool small_tables = !(getenv("CS_KMAP_SMALL") && getenv("CS_KMAP_SMALL")[0] == '0');
+          if (small_tables && need <= 2048 / 8 * 5)
+            hipLaunchKernelGGL((k_build_nbr_lds<2048, 256>), dim3((unsigned)slices, (unsigned)nb), dim3(256), 0, s,
+                               in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
+                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+          else if (small_tables && need <= 8192 / 8 * 5)
+            hipLaunchKernelGGL((k_build_nbr_lds<8192, 512>), dim3((unsigned)slices, (unsigned)nb), dim3(512), 0, s,
+                               in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
+                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+          else
+            hipLaunchKernelGGL((k_build_nbr_lds<LDS_SLOTS_MAX, 1024>), dim3((unsigned)slices, (unsigned)nb), dim3(1024),
+                               0, s, in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
+                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
           hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, out->d_coords,
                              out_m->d_seg, step, sign, in->d_keys, in->d_vals, in->capacity - 1,
                              km->d_nbr, cnt_p, fb_p);
