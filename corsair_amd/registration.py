@@ -45,6 +45,19 @@ class SymPoseResult:
     ok: np.ndarray              # bool [P]  (sym_ransac_success)
     iters: torch.Tensor         # int32 [n_problems] RANSAC iterations consumed
     n_problems: int
+    # every hypothesis evaluated (problem j): the first P are the vanilla find_kcorr RANSACs of the pairs,
+    # then the part configurations of the pairs whose cut passed, pair-major, in the reference's order
+    # (utils/symmetry.py:303-356)
+    T_all: torch.Tensor = None      # f32 [n_problems,4,4]
+    cd_all: torch.Tensor = None     # f64 [n_problems]
+    inliers: torch.Tensor = None    # int32 [n_problems]
+    prob_pair: list = None          # pair of problem j
+    prob_cfg: list = None           # part assignment of problem j (None = vanilla)
+    best: np.ndarray = None         # int64 [P] problem kept per pair (first strict Chamfer minimum)
+
+    def hypotheses(self, p):
+        """Problems of pair p in evaluation order."""
+        return [j for j, q in enumerate(self.prob_pair) if q == p]
 
 
 def draw_anchors(n, n_anchor, counter):
@@ -159,6 +172,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
     prob_tgt = [tgt_rows]
     prob_len = [n0[p] * k for p in range(P)]
     prob_pair = list(range(P))
+    prob_cfg = [None] * P
     ok = np.zeros(P, dtype=bool)
     vanilla = None
     if use_symmetry and dev.type == "cuda" and os.environ.get("CORSAIR_SPLIT_RANSAC", "1") != "0":
@@ -249,6 +263,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
                     for j in keep:
                         prob_len.append(n0[cfg_pair[j]] * k)
                         prob_pair.append(cfg_pair[j])
+                        prob_cfg.append([c for c in perms[j] if c >= 0])
     except BaseException:
         if vanilla is not None:       # do not leave the helper's call running into freed tensors
             try:
@@ -290,4 +305,5 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
             best[p] = j
     best_t = torch.from_numpy(best).to(dev)
     return SymPoseResult(T_best=T[best_t], cd_best=cd[best_t], T_ransac=T[:P], cd_ransac=cd[:P],
-                         ok=ok, iters=iters, n_problems=len(prob_pair))
+                         ok=ok, iters=iters, n_problems=len(prob_pair), T_all=T, cd_all=cd, inliers=inl,
+                         prob_pair=prob_pair, prob_cfg=prob_cfg, best=best)

@@ -133,14 +133,35 @@ def split_corr(xyz0, xyz1, F0, F1, lab0, lab1, perm, knn):
     return xyz0[np.repeat(order, knn)], xyz1[idx.reshape(-1)]
 
 
+def part_configs(K, pos_sym):
+    """Part assignments tried after the vanilla RANSAC: K cyclic shifts of pos_masks (utils/symmetry.py:303-324,
+    `pos_masks = pos_masks[1:] + pos_masks[:1]`), then -- pos_sym >= 2 only -- 4 shifts of the mirrored order
+    `[pos_masks[0], pos_masks[3], pos_masks[2], pos_masks[1]]` (utils/symmetry.py:326-356)."""
+    configs = [[(i + s) % K for i in range(K)] for s in range(K)]
+    if pos_sym >= 2:
+        mirror = [0, 3, 2, 1]
+        configs += [[mirror[(i + s) % 4] for i in range(4)] for s in range(4)]
+    return configs
+
+
 def sym_pose(baseF, xyz0, posF, xyz1, pos_sym, k_nn=5, max_corr=0.20, seed=0, anchors0=None,
-             anchors1=None, max_iter=100000, confidence=0.999, force_gate=False):
+             anchors1=None, max_iter=100000, confidence=0.999, force_gate=False, return_hyps=False):
     """utils/symmetry.py:262-358.  anchors0/anchors1: int32 anchor rows for the two clouds (None
-    -> the cut fails like an exception in the reference)."""
+    -> the cut fails like an exception in the reference).
+    return_hyps: also return the list of every hypothesis evaluated, in evaluation order, as dicts
+    {config (None = vanilla find_kcorr RANSAC), T f32[4,4], cd, iters, inliers, n_corr}, and the index
+    of the one kept (first strict minimum of the Chamfer distance, utils/symmetry.py:322-324)."""
     idx_0, idx_1 = find_kcorr(baseF, posF, k=k_nn)
-    T_ransac = registration_based_on_corr(xyz0[idx_0], xyz1[idx_1], max_corr, seed, max_iter, confidence)
+    T_ransac, inl, _, it = native.ransac(xyz0[idx_0], xyz1[idx_1], max_corr, 10, max_iter, confidence, seed)
     cd_ransac = chamfer_kdtree_1direction_T(xyz0, T_ransac, xyz1)
     T_best, cd_best = T_ransac, cd_ransac
+    hyps = [dict(config=None, T=T_ransac, cd=cd_ransac, iters=it, inliers=inl, n_corr=len(idx_0))]
+    chosen = 0
+
+    def done(ok):
+        out = (T_best, cd_best, T_ransac, cd_ransac, ok)
+        return out + (hyps, chosen) if return_hyps else out
+
     K = 4 if pos_sym >= 2 else 2
     try:
         if anchors0 is None or anchors1 is None:
@@ -148,20 +169,18 @@ def sym_pose(baseF, xyz0, posF, xyz1, pos_sym, k_nn=5, max_corr=0.20, seed=0, an
         lab0 = symmetric_cut4(baseF, xyz0, K, anchors0, seed=0, force_gate=force_gate)
         lab1 = symmetric_cut4(posF, xyz1, K, anchors1, seed=0, force_gate=force_gate)
     except (AttributeError, ValueError):
-        return T_best, cd_best, T_ransac, cd_ransac, False
-    configs = [[(i + s) % K for i in range(K)] for s in range(K)]
-    if pos_sym >= 2:
-        mirror = [0, 3, 2, 1]
-        configs += [[mirror[(i + s) % 4] for i in range(4)] for s in range(4)]
-    for perm in configs:
+        return done(False)
+    for perm in part_configs(K, pos_sym):
         corr = split_corr(xyz0, xyz1, baseF, posF, lab0, lab1, perm, k_nn)
         if corr is None:
             continue
-        T = registration_based_on_corr(corr[0], corr[1], max_corr, seed, max_iter, confidence)
+        T, inl, _, it = native.ransac(corr[0], corr[1], max_corr, 10, max_iter, confidence, seed)
         cd = chamfer_kdtree_1direction_T(xyz0, T, xyz1)
+        hyps.append(dict(config=list(perm), T=T, cd=cd, iters=it, inliers=inl, n_corr=len(corr[0])))
         if cd_best > cd:
             cd_best, T_best = cd, T
-    return T_best, cd_best, T_ransac, cd_ransac, True
+            chosen = len(hyps) - 1
+    return done(True)
 
 
 # ---- pose metrics --------------------------------------------------------------------------------

@@ -114,21 +114,16 @@ def _pairs(rng, m, inlier_frac, noise, pose_id):
 
 
 def _recount(src, tgt, T, max_corr):
-    """Inlier count and rmse under T with the library's canonical f32 chain."""
-    f = np.float32
-    R, t = T[:3, :3].astype(f), T[:3, 3].astype(f)
-    d = np.empty((len(src), 3), f)
-    for c in range(3):
-        acc = (R[c, 0] * src[:, 0]).astype(np.float64) - tgt[:, c].astype(np.float64)   # fma(r0, sx, -q)
-        acc = acc.astype(f)
-        acc = (R[c, 1].astype(np.float64) * src[:, 1] + acc).astype(f)
-        acc = (R[c, 2].astype(np.float64) * src[:, 2] + acc).astype(f)
-        d[:, c] = (acc + t[c]).astype(f)
-    d2 = (d[:, 0].astype(np.float64) * d[:, 0]).astype(f)
-    d2 = (d[:, 1].astype(np.float64) * d[:, 1] + d2).astype(f)
-    d2 = (d[:, 2].astype(np.float64) * d[:, 2] + d2).astype(f)
-    inl = d2 < f(max_corr) * f(max_corr)
-    return int(inl.sum())
+    """f64 inlier recount under the RETURNED transform.  The library counts in f64 under the f64
+    hypothesis (Open3D's arithmetic, DESIGN "Canonical arithmetic") and casts the winner to f32 only at
+    the end, where the reference casts it (utils/symmetry.py:274); the returned f32 T therefore differs
+    from the counted one by f32 rounding, which moves a residual by < 1e-6 here.  Returns (count,
+    number of pairs whose squared residual is within 1e-5 of the threshold = pairs the rounding may flip)."""
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    d = src.astype(np.float64) @ R.T + t - tgt.astype(np.float64)
+    d2 = (d * d).sum(1)
+    thr2 = float(max_corr) * float(max_corr)
+    return int((d2 < thr2).sum()), int((np.abs(d2 - thr2) < 1e-5).sum())
 
 
 def test_ransac_full_size_round_trip_and_prefilter_invariance(gpu, monkeypatch):
@@ -161,7 +156,9 @@ def test_ransac_full_size_round_trip_and_prefilter_invariance(gpu, monkeypatch):
     assert np.abs(T[0][:3, 3] - probs[0][2][:3, 3]).max() < 0.15
     assert inl[0] > 0.4 * 22700
     for p, (src, tgt, _) in enumerate(probs):
-        assert _recount(src, tgt, T[p], 0.2) == inl[p], p
+        cnt, borderline = _recount(src, tgt, T[p], 0.2)
+        assert abs(cnt - int(inl[p])) <= borderline, (p, cnt, int(inl[p]), borderline)
+        assert borderline < 20
 
 
 def test_knn_and_chamfer_full_size_properties(gpu):
