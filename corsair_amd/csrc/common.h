@@ -106,6 +106,33 @@ __host__ __device__ static inline uint64_t hash64(uint64_t k) {
 }
 static constexpr uint64_t kEmptyKey = ~0ULL;
 
+// LDS-DMA of 64 x 16 B (global_load_lds_dwordx4): lane l's 16 bytes at g land at LDS byte address
+// lds_addr + 16 l (lds_addr wave-uniform, in an SGPR).  Written as inline asm ON PURPOSE: behind the
+// __builtin_amdgcn_global_load_lds form hipcc (ROCm 7.2) treats the DMA as a pending LDS write that may
+// alias every later ds_read and puts `s_waitcnt vmcnt(0)` in front of the first one -- a stage issued
+// "one chunk ahead" is then waited for before the current chunk is computed.  The asm form is invisible
+// to that pass: the caller orders the data itself (s_waitcnt vmcnt(0) by every issuing wave, then a
+// workgroup barrier, before anyone reads the staged bytes).  No "memory" clobber: ordinary LDS reads of
+// OTHER bytes may be scheduled across the DMA (that is the point of issuing it early); volatile asm keeps
+// its order against the barrier / s_waitcnt statements, which is all the protocol needs.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // wave-uniform by contract; the "s" operand needs an SGPR
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr)
+               : "m0");
+#endif
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+#else
+  return 0;
+#endif
+}
+
 }  // namespace cs
 
 struct cs_coordmap {

@@ -23,6 +23,9 @@
 //   * epilogue (BN affine / bias, residual add, ReLU) is applied to the accumulators and written
 //     with an arbitrary leading dimension so decoder outputs land directly in the concat buffer.
 #include "common.h"
+#include <type_traits>
+#include <vector>
+#include <algorithm>
 
 namespace cs {
 
@@ -200,228 +203,396 @@ __global__ __launch_bounds__(256) void k_conv_mfma(
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_conv_lacc: sparse convolution with accumulators in LDS and per-offset ROW COMPACTION (round 2).
+// k_conv_dma<RG, CG, NT>: the production kernel of the 3x3x3 / strided / transposed / 1x1 convolutions
+// (round 3).  Same arithmetic as k_conv_mfma (one v_mfma_f32_32x32x2_f32 chain per output element,
+// k = 0..26 outer, ci ascending inner: bit-identical to the oracle), different machinery around it:
 //
-// k_conv_mfma keeps a tile's accumulators in registers, so every row of a tile pays the MFMA time of
-// every offset the TILE uses: x1.6 - 2.2 of the useful work on real occupancy (a voxel has ~10 of its 27
-// neighbours).  Here a WAVE owns 64 output rows x TN channels whose accumulators live in its private
-// slice of LDS; for every offset k the rows that have neighbour k are compacted (ballot + mbcnt: lane =
-// row) and only they go through the matrix pipe, 32 at a time:
-//     C  <- LDS accumulator rows of the group      (v_mfma_f32_32x32x2_f32 accumulator INPUT)
-//     C  <- the fma chain over the Cin channels    (same chain, same order: bit-identical results)
-//     LDS <- C
-// Executed / useful MFMA work on the bench clouds: 1.2 - 1.6 (mask-sorted rows), against 1.6 - 2.6.
-// No workgroup barrier anywhere: the four waves of a workgroup are independent (LDS is wave-private,
-// LDS operations of one wave execute in order), so a wave never waits for its neighbours' gathers.
-// Operands come straight from global memory / L2, no LDS staging:
-//   * A (gathered input rows): lane (half h, row j) loads channels [16 h, 16 h + 16) of its row with four
-//     16-byte loads; MFMA i of the 32-channel chunk needs channel 2 i + h in lane (h, j), which is what ONE
-//     v_permlane32_swap per register pair produces: swap(X[2m], X[2m+1]) leaves (ch 2m | ch 2m+1) in the
-//     first register = operand of MFMA m, and (ch 16+2m | ch 17+2m) in the second = operand of MFMA 8+m.
-//   * B (weights W[k][ci][co], reference layout): lane (h, c) reads W[k][ci0 + 2 i + h][n0 + 32 t + c]:
-//     two coalesced 128-byte rows per MFMA, L2-resident (a layer's weights are 27 Cin Cout 4 B <= 7 MB).
-// The next chunk's A and B registers are loaded while the current chunk's MFMAs run.
+//   * staging by LDS-DMA (global_load_lds_dwordx4): gathered input rows and the weight slab of a
+//     32-channel chunk go HBM/L2 -> LDS without passing through VGPRs and without ds_write; two stage
+//     buffers, the DMA of chunk c+1 is in flight while chunk c is on the matrix pipe; one barrier per
+//     chunk.  The gathered rows form a 128-B-pitch image (a DMA instruction writes 64 x 16 B
+//     contiguously: 8 rows); bank conflicts of the A-fragment reads are removed on the SOURCE side:
+//     slot p of row r holds channels 4 (p ^ ((r >> 1) & 7)) .. +3, so the ds_read_b128 of one 4-channel
+//     piece by 32 lanes = 32 rows touches every bank group once.  One ds_read_b128 feeds two MFMA
+//     k-steps (channels 4j + h and 4j + 2 + h for lane half h).  Absent neighbours read a zero row.
+//   * a wave owns ONE 32-row group (x 32 NT columns) and skips every chunk of an offset none of ITS
+//     32 rows has; the workgroup (RG row groups x CG column groups = 4 waves) walks the union of its
+//     groups' offsets in lock step for the shared weight slab, but the matrix pipe only sees the
+//     per-group work.  With rows ordered by the full 27-bit neighbour mask a 32-row group executes
+//     1.2 - 1.5x its useful MFMAs (64-row tiles of the 12-bit order: 1.7 - 2.3x); the SIMD a skipping
+//     wave leaves idle is taken by the other workgroups resident on the CU.
+//   * tiles: RG x CG = 4 x 1 (128 rows x 32/64 columns) for the fine levels, 2 x 2 and 1 x 4 where a
+//     layer has too few rows to fill the chip with 128-row tiles.
 // ------------------------------------------------------------------------------------------------
-#ifndef CONV_DBG
-#define CONV_DBG 0   // timing experiments only (tools/conv_dbg.sh): 1 no A loads, 2 no B loads, 4 no MFMAs
+__device__ __attribute__((aligned(128))) float g_zero_row[32] = {0.f};
+
+template <int RG, int CG, int NT>
+struct ConvDmaCfg {
+  static constexpr int TM = 32 * RG;
+  static constexpr int TN = 32 * NT * CG;
+  static constexpr int A_BYTES = TM * 128;           // 32 channels x 4 B per row
+  static constexpr int B_BYTES = TN * 128;           // 32 slab rows x TN x 4 B
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // nothing else lives in LDS: 32 - 48 KB, 3 - 5 workgroups per CU
+};
+
+// n LDS-DMA instructions of 1 KiB in ONE asm statement (a volatile asm is a scheduling barrier for hipcc:
+// one per chunk instead of one per instruction leaves the LDS reads, MFMAs and address arithmetic of a chunk
+// in a single region the scheduler can interleave).  Piece i lands at lds + i * STRIDE.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int N, int STRIDE>
+__device__ __forceinline__ void lds_dma16_block(const float* const (&g)[N], unsigned lds) {
+  static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 pieces");
+#if defined(__HIP_DEVICE_COMPILE__)
+  lds = __builtin_amdgcn_readfirstlane(lds);
+  if constexpr (N == 1) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g[0]), "s"(lds) : "m0");
+  } else if constexpr (N == 2) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+        "s_add_u32 m0, m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"v"(g[0]),
+        "v"(g[1]), "s"(lds), "n"(STRIDE)
+        : "m0", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+        "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off" ::"v"(g[0]),
+        "v"(g[1]), "v"(g[2]), "v"(g[3]), "s"(lds), "n"(STRIDE)
+        : "m0", "scc");
+  }
 #endif
-template <int NT>
-__global__ __launch_bounds__(256) void k_conv_lacc(
+}
+#pragma clang diagnostic pop
+
+template <int RG, int CG, int NT, bool GATHER, bool TRACE>
+__global__ __launch_bounds__(256) void k_conv_dma(
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist, int kvol, int64_t n_out,
     const float* __restrict__ in, int ld_in, int cin, const float* __restrict__ w, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out, int ld_out) {
-  constexpr int TN = 32 * NT;
-  constexpr int R = 64;                    // output rows per wave (lane = row)
-  constexpr int DUMMY = R;                 // accumulator row of the padded slots of a group
-  // dynamic LDS: 4 waves x ((R + 1) x TN floats + 2 lists x R uint16) = 66 KiB for TN = 64
-  extern __shared__ __attribute__((aligned(16))) char lacc_lds[];
-  constexpr int ROWB = TN * 4;             // bytes per accumulator row
-  constexpr int WAVE_BYTES = (R + 1) * ROWB + 2 * R * 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = lane >> 5, c = lane & 31;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * R;
-  if (row0 >= n_out) return;               // whole wave; no barriers below
+    const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out, int ld_out,
+    unsigned long long* __restrict__ trace) {
+  using C = ConvDmaCfg<RG, CG, NT>;
+  constexpr int TM = C::TM, TN = C::TN;
+  static_assert(RG * CG == 4, "4 waves");
+  constexpr int A_PIECES = 4 / CG;          // 1-KiB DMA instructions per wave for its row group's 32 rows
+  constexpr int B_PIECES = TN / 32;         // ... and for the weight slab (TN / 8 pieces over 4 waves)
+  constexpr int K_END = 32;                 // sentinel offset: no chunk left
+  // ONE LDS object (a second one beside a DMA-staged array can make hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(128))) char lds[C::LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS addresses of the DMA stay in SGPRs
+  const int rg = wave / CG;
+  const int cg = wave % CG;
+  const int half = lane >> 5;
+  const int rl = lane & 31;
+  const int64_t row0 = (int64_t)blockIdx.x * TM;
   const int n0 = blockIdx.y * TN;
-  char* ACCB = lacc_lds + wave * WAVE_BYTES;                              // accumulators, byte-addressed
-  unsigned short* LIST = reinterpret_cast<unsigned short*>(ACCB + (R + 1) * ROWB);   // [2][R] byte offsets of rows
+  const int cchunks = cin / 32;
 
-  // this lane's output row, its 27 neighbour rows (registers) and their presence mask
-  int o = -1;
-  if (row0 + lane < n_out) o = rowlist ? rowlist[row0 + lane] : (int)(row0 + lane);
-  int nb[27];
-  unsigned mask = 0;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    nb[k] = (o >= 0 && k < kvol) ? nbr[(int64_t)o * kvol + k] : -1;
-    mask |= (nb[k] >= 0 ? 1u : 0u) << k;
-  }
+  // ---- rows of this wave's group, offsets they use ----
+  // lane (rl, half): output row of group slot rl; both halves hold the same row
+  int32_t my_o = -1;
   {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < TN / 4; ++q) *reinterpret_cast<float4*>(ACCB + lane * ROWB + 16 * q) = z;
-    if (lane < TN / 4) *reinterpret_cast<float4*>(ACCB + DUMMY * ROWB + 16 * lane) = z;
+    const int64_t t = row0 + rg * 32 + rl;
+    if (t < n_out) my_o = rowlist ? rowlist[t] : (int32_t)t;
   }
-  const int cchunks = cin >> 5;
+  unsigned mymask = 0;
+  if (GATHER) {
+    // 27 independent loads per lane (rows past the end read row 0 and are masked out)
+    const int64_t o = my_o >= 0 ? my_o : 0;
+    int32_t v[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = nbr[o * kvol + (k < kvol ? k : 0)];   // (no load under a condition)
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mymask |= (my_o >= 0 && k < kvol && v[k] >= 0 ? 1u : 0u) << k;
+  } else {
+    mymask = my_o >= 0 ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) mymask |= __shfl_xor(mymask, off);
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  // union over the workgroup's groups through the (still unused) stage memory
+  unsigned* gm_lds = reinterpret_cast<unsigned*>(lds);
+  if (lane == 0) gm_lds[wave] = mymask;
+  __syncthreads();
+  const unsigned kmask = __builtin_amdgcn_readfirstlane(gm_lds[0] | gm_lds[1] | gm_lds[2] | gm_lds[3]);
+  __syncthreads();
 
-  // first offset >= from that some row of this wave has (wave-uniform), 27 = none
-  auto next_k = [&](int from) {
-    int kk = from;
-    while (kk < kvol && __ballot((mask >> kk) & 1u) == 0ULL) ++kk;
-    return kk < kvol ? kk : 27;
-  };
-  // compacted list of the rows that have offset kk, as byte offsets of their accumulator rows, padded with the
-  // DUMMY row to whole groups of 32 -> LIST[buf][0 .. ceil32(count)); nbk = this lane's neighbour for kk
-  auto build_list = [&](int kk, int buf, int& nbk) {
-    const bool has = (mask >> kk) & 1u;
-    const unsigned long long bal = __ballot(has);
-    const int cnt = (int)__popcll(bal);
-    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-    if (has) LIST[buf * R + pos] = (unsigned short)(lane * ROWB);
-    if (lane >= cnt && lane < ((cnt + 31) & ~31)) LIST[buf * R + lane] = (unsigned short)(DUMMY * ROWB);
-    nbk = nb[0];
+  // DMA geometry.  A: piece i of this wave covers rows 8 (cg A_PIECES + i) .. + 7 of group rg; lane ->
+  // (row = lane >> 3, slot = lane & 7), source channels 4 (slot ^ ((row_in_group >> 1) & 7)) .. + 3.
+  // B: piece p = wave + 4 j, float index p * 256 + 4 lane of the [32][TN] slab.
+  int64_t a_o[A_PIECES];        // output row whose neighbour this lane fetches for piece i (-1: none)
+  int a_c4[A_PIECES];
 #pragma unroll
-    for (int q = 1; q < 27; ++q) nbk = kk == q ? nb[q] : nbk;   // uniform selects, once per offset
-    __builtin_amdgcn_wave_barrier();       // (compiler ordering only: same-wave LDS ops execute in order)
-    return cnt;
-  };
-  // input row this lane gathers for group (g0 of the list in buf): compacted slot g0 + c (both halves: the
-  // same row).  Padded slots read some valid row: their products land in the DUMMY accumulator row and are
-  // never used, so the loads need no predicate (an exec-masked load puts a branch and a register merge into
-  // the pipeline).
-  auto prep = [&](int nbk, int g0, int buf) -> const float* {
-    const int rho = (int)LIST[buf * R + g0 + c] / ROWB;   // owner lane of the row (DUMMY -> 64 -> lane 0)
-    const int src = max(__shfl(nbk, rho), 0);
-    return in + (int64_t)src * ld_in + 16 * h;
-  };
-  auto load_a = [&](const float* p4, float4 (&dst)[4]) {
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
+    a_o[i] = __shfl(my_o, r);
+    a_c4[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+  }
+  const float* b_lane[B_PIECES];   // this lane's element of slab row 0 of (k = 0, cc = 0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dst[q] = (CONV_DBG & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p4 + 4 * q);
-  };
-  // B operand: uniform base (SGPRs) + one per-lane 32-bit offset shared by every load
-  const int loff = h * cout + c;
-  auto wslab = [&](int kk, int cc) { return w + ((int64_t)kk * cin + cc * 32) * cout + n0; };   // wave-uniform
+  for (int j = 0; j < B_PIECES; ++j) {
+    const int f = (wave + 4 * j) * 256 + 4 * lane;
+    const int sr = f / TN;
+    b_lane[j] = w + (int64_t)sr * cout + n0 + (f - sr * TN);
+  }
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  const unsigned a_lds = lds_base + rg * 4096 + cg * A_PIECES * 1024;
+  const unsigned b_lds = lds_base + C::A_BYTES + wave * 1024;
 
-  int k = next_k(0);
-  if (k < 27) {
-    int buf = 0, g0 = 0, nbk = 0, nnbk = 0;
-    int mk = build_list(k, buf, nbk);
-    const float* arow = prep(nbk, g0, buf);
-    float4 x[4];
-    float b[16][NT];
-    load_a(arow, x);
-    {
-      const float* wu = wslab(k, 0);
+  // chunk stepping without branches: next offset of the union above k, K_END when there is none
+  auto step = [&](int& k, int& cc) {
+    const int c1 = cc + 1;
+    const bool wrap = c1 == cchunks;
+    const unsigned rest = k < 31 ? kmask >> (k + 1) : 0u;
+    const int knext = rest ? k + 1 + __builtin_ctz(rest) : K_END;
+    cc = wrap ? 0 : c1;
+    k = k >= K_END ? K_END : (wrap ? knext : k);
+  };
+  // source rows of the A pieces of offset k (plain loads, consumed one iteration later)
+  auto fetch_src = [&](int k, int32_t (&src)[A_PIECES]) {
+    // GATHER is a template flag, not a test of `nbr`: a load inside a run-time branch is waited for
+    // (vmcnt(0): the DMA issued just before it included) where the branch ends
+    const int kc = k < kvol ? k : 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < A_PIECES; ++i)
+      src[i] = GATHER ? nbr[(a_o[i] >= 0 ? a_o[i] : 0) * kvol + kc] : (int32_t)a_o[i];
+  };
+  // DMA source pointers of chunk (k, cc): gathered rows (a group without offset k, absent neighbours and
+  // rows past the end stage the zero row) and the weight slab
+  auto a_ptrs = [&](int k, int cc, const int32_t (&src)[A_PIECES], const float* (&pa)[A_PIECES]) {
+    const bool grp = k < K_END && ((mymask >> k) & 1u);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[i][t] = (CONV_DBG & 2) ? 1.0f : (wu + (int64_t)(2 * i) * cout + 32 * t)[loff];
+    for (int i = 0; i < A_PIECES; ++i) {
+      // (both candidates are computed, then selected: no branch around the 64-bit multiply)
+      const bool live = grp && a_o[i] >= 0 && src[i] >= 0;
+      const float* row = in + (int64_t)(src[i] >= 0 ? src[i] : 0) * ld_in + cc * 32;
+      pa[i] = (live ? row : g_zero_row) + a_c4[i];
     }
-    bool more = true;
-    while (more) {
-      // LDS byte addresses of the accumulator rows of this lane's 16 result registers: slots
-      // (i & 3) + 8 (i >> 2) + 4 h of the group, column c
-      unsigned addr[16];
+  };
+  auto b_ptrs = [&](int k, int cc, const float* (&pb)[B_PIECES]) {
+    const int64_t off = ((int64_t)(k < K_END ? k : 0) * cin + cc * 32) * cout;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint2 pr = *reinterpret_cast<const uint2*>(&LIST[buf * R + g0 + 8 * q + 4 * h]);
-        addr[4 * q + 0] = (pr.x & 0xffffu) + 4 * c;
-        addr[4 * q + 1] = (pr.x >> 16) + 4 * c;
-        addr[4 * q + 2] = (pr.y & 0xffffu) + 4 * c;
-        addr[4 * q + 3] = (pr.y >> 16) + 4 * c;
-      }
-      f32x16 acc[NT];
+    for (int j = 0; j < B_PIECES; ++j) pb[j] = b_lane[j] + off;
+  };
+
+  f32x16 acc[NT];
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t][i] = *reinterpret_cast<const float*>(ACCB + addr[i] + 128 * t);
-      // the group after this one: its first operands are requested under this group's last chunk
-      int nk = k, ng0 = g0 + 32, nmk = mk, nbuf = buf;
-      nnbk = nbk;
-      if (ng0 >= mk) {
-        nk = next_k(k + 1);
-        ng0 = 0;
-        nbuf = buf ^ 1;
-        if (nk < 27) nmk = build_list(nk, nbuf, nnbk);
-      }
-      more = nk < 27;
-      const int kn = more ? nk : k;         // (after the last group: harmless re-reads of valid addresses)
-      const float* narow = more ? prep(nnbk, ng0, nbuf) : arow;
-      for (int cc = 0; cc < cchunks; ++cc) {
-        float a[16];
-        {
-          const float X[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
-                               x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  // chunk c = (k, cc), c + 1 = (nk, ncc), c + 2 = (k2, cc2)
+  int k = kmask ? __builtin_ctz(kmask) : K_END, cc = 0;
+  int nk = k, ncc = cc;
+  step(nk, ncc);
+  int k2 = nk, cc2 = ncc;
+  step(k2, cc2);
+  const float* pa_n[A_PIECES];     // pointers of the chunk staged next (c + 1)
+  const float* pb_n[B_PIECES];
+  int32_t src2[A_PIECES];          // source rows of chunk c + 2
+  if (k < K_END) {
+    int32_t s0[A_PIECES], s1[A_PIECES];
+    fetch_src(k, s0);
+    fetch_src(nk, s1);
+    fetch_src(k2, src2);
+    const float* pa0[A_PIECES];
+    const float* pb0[B_PIECES];
+    a_ptrs(k, 0, s0, pa0);
+    b_ptrs(k, 0, pb0);
+    lds_dma16_block<A_PIECES, 1024>(pa0, a_lds);
+    lds_dma16_block<B_PIECES, 4096>(pb0, b_lds);
+    a_ptrs(nk, ncc, s1, pa_n);
+    b_ptrs(nk, ncc, pb_n);
+  }
+  const int swz = (rl >> 1) & 7;
+  int buf = 0;
+  unsigned long long t_start = 0, t_wait = 0, t_vm = 0, t_body = 0, n_chunk = 0, n_act = 0, t_dma = 0, t_mfma = 0;
+  if (TRACE) t_start = __builtin_amdgcn_s_memtime();
+  while (k < K_END) {
+    // the DMA of this chunk has landed (every wave waits for its own pieces, then the barrier) and every
+    // wave is done reading the other buffer (it read it before arriving here)
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (TRACE) t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TRACE) t1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (TRACE) t2 = __builtin_amdgcn_s_memtime();
+    // pointers of chunk c + 2 from the source rows fetched one iteration ago, BEFORE this iteration puts
+    // anything on the memory queue: hipcc's own wait for those (long finished) loads is then a no-op; issued
+    // behind the DMAs its counted vmcnt would wait for the DMAs instead
+    const float* pa_nn[A_PIECES];
+    const float* pb_nn[B_PIECES];
+    a_ptrs(k2, cc2, src2, pa_nn);
+    b_ptrs(k2, cc2, pb_nn);
 #pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[2 * m]), __float_as_uint(X[2 * m + 1]),
-                                                             false, false);
-            a[m] = __uint_as_float(sw[0]);
-            a[8 + m] = __uint_as_float(sw[1]);
-          }
+    for (int i = 0; i < A_PIECES; ++i) asm volatile("" ::"v"(pa_nn[i]));
+    // source rows of chunk c + 3 (used one iteration from now)
+    int k3 = k2, cc3 = cc2;
+    step(k3, cc3);
+    fetch_src(k3, src2);
+    unsigned long long t3 = 0, t4 = 0;
+    if (TRACE) t3 = __builtin_amdgcn_s_memtime();
+    const bool stage_next = nk < K_END;
+    const unsigned a_dst = a_lds + (buf ^ 1) * C::STAGE_BYTES, b_dst = b_lds + (buf ^ 1) * C::STAGE_BYTES;
+    const bool active = (mymask >> k) & 1u;
+    if (active) {
+      // one chunk on the matrix pipe.  Hand-placed software pipeline (the volatile DMA statements pin the order):
+      // fragment reads run two steps ahead of their MFMAs, one DMA instruction of the next stage goes out
+      // behind the MFMAs of each of the first A_PIECES + B_PIECES steps -- its issue cost hides under the
+      // 64-cycle MFMAs instead of standing in front of them, and the CU's DMA traffic is not one burst
+      // right behind the barrier
+      const char* stage = lds + buf * C::STAGE_BYTES;
+      const float* a_row = reinterpret_cast<const float*>(stage + rg * 4096) + rl * 32;
+      const float* b_base = reinterpret_cast<const float*>(stage + C::A_BYTES) + half * TN + cg * 32 * NT + rl;
+      float4 av[8];
+      float bv[16][NT];
+      auto rd = [&](int j) {
+        av[j] = *reinterpret_cast<const float4*>(a_row + ((j ^ swz) << 2));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          bv[2 * j][t] = b_base[(4 * j) * TN + t * 32];
+          bv[2 * j + 1][t] = b_base[(4 * j + 2) * TN + t * 32];
         }
-        // operands of the chunk after this one (next chunk of the group, or first chunk of the next group):
-        // one branch-free set of loads; every B register is reloaded right behind the MFMA that consumed it
-        const bool last = cc + 1 == cchunks;
-        const float* pa = last ? narow : arow + (cc + 1) * 32;
-        const float* wu = last ? wslab(kn, 0) : wslab(k, cc + 1);
-        load_a(pa, x);
+      };
+      rd(0);
+      rd(1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 8; ++j) {
+        if (j + 2 < 8) rd(j + 2);
+        const float a0 = half ? av[j].y : av[j].x;
+        const float a1 = half ? av[j].w : av[j].z;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (CONV_DBG & 4)
-              acc[t][i] += a[i] * b[i][t];
-            else
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][t], acc[t], 0, 0, 0);
-            b[i][t] = (CONV_DBG & 2) ? 1.0f : (wu + (int64_t)(2 * i) * cout + 32 * t)[loff];
-          }
-        // keep that order: one MFMA, then the reload of the register it consumed (hipcc otherwise sinks all the
-        // loads below the MFMA block, where the next chunk waits a full L2 latency for them)
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 16 * NT; ++j) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[2 * j + 1][t], acc[t], 0, 0, 0);
+        if (stage_next) {
+          if (j < A_PIECES)
+            lds_dma16(pa_n[j], a_dst + j * 1024);
+          else if (j < A_PIECES + B_PIECES)
+            lds_dma16(pb_n[j - A_PIECES], b_dst + (j - A_PIECES) * 4096);
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) *reinterpret_cast<float*>(ACCB + addr[i] + 128 * t) = acc[t][i];
-      __builtin_amdgcn_wave_barrier();
-      k = nk;
-      g0 = ng0;
-      mk = nmk;
-      buf = nbuf;
-      nbk = nnbk;
-      arow = narow;
+    } else if (stage_next) {
+      lds_dma16_block<A_PIECES, 1024>(pa_n, a_dst);
+      lds_dma16_block<B_PIECES, 4096>(pb_n, b_dst);
     }
+    if (TRACE) t4 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) pa_n[i] = pa_nn[i];
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) pb_n[j] = pb_nn[j];
+    if (TRACE) {
+      t_vm += t1 - t0;
+      t_wait += t2 - t1;
+      t_body += __builtin_amdgcn_s_memtime() - t2;
+      t_dma += t3 - t2;
+      t_mfma += t4 - t3;
+      ++n_chunk;
+      n_act += active;
+    }
+    k = nk; cc = ncc;
+    nk = k2; ncc = cc2;
+    k2 = k3; cc2 = cc3;
+    buf ^= 1;
+  }
+  if (TRACE && lane == 0) {
+    unsigned long long* tr = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    tr[0] = __builtin_amdgcn_s_memtime() - t_start; tr[1] = t_vm; tr[2] = t_wait; tr[3] = t_body; tr[4] = n_chunk;
+    tr[5] = n_act; tr[6] = t_dma; tr[7] = t_mfma;
   }
 
-  // epilogue: row-major LDS -> coalesced global rows (64 / TN rows per pass)
-  {
-    constexpr int RPP = 64 / TN;            // rows per pass
-    const int col = n0 + (lane & (TN - 1));
-    const int sub = lane / TN;
-    const float sc = scale ? scale[col] : 1.0f;
-    const float sh = shift ? shift[col] : 0.0f;
-    for (int r0 = 0; r0 < R; r0 += RPP) {
-      const int r = r0 + sub;
-      const int o_r = __shfl(o, r);
-      if (o_r < 0) continue;
-      float v = *reinterpret_cast<const float*>(ACCB + r * ROWB + 4 * (lane & (TN - 1)));
+  // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  The residual
+  // values of the 16 rows are requested together and unconditionally (rows past the end read the tile's
+  // first row): a load under a per-row condition is waited for before the next one is issued.
+  int32_t orow[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) orow[i] = __shfl(my_o, (i & 3) + 8 * (i >> 2) + 4 * half);
+  const int32_t o_safe = rowlist ? rowlist[row0] : (int32_t)row0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + cg * 32 * NT + t * 32 + (lane & 31);
+    float res[16];
+    if (residual) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        res[i] = residual[(int64_t)(orow[i] >= 0 ? orow[i] : o_safe) * ld_res + col];
+    }
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = shift ? shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = acc[t][i];
       if (scale)
         v = __fmaf_rn(v, sc, sh);
       else if (shift)
         v = v + sh;
-      if (residual) v = v + residual[(int64_t)o_r * ld_res + col];
+      if (residual) v = v + res[i];
       if (relu) v = fmaxf(v, 0.0f);
-      out[(int64_t)o_r * ld_out + col] = v;
+      if (orow[i] >= 0) out[(int64_t)orow[i] * ld_out + col] = v;
     }
   }
 }
+
+// Cin = 1 (the 1 -> 32 stem, model/resunet.py:49-57): a 27-term fma chain per output.  A lane first
+// gathers the <= 27 scalar inputs of ITS row (27 independent loads in flight), the wave shares them
+// through LDS and then every lane owns one output channel (its 27 weights in registers) and walks the
+// wave's 64 rows: stores are whole 128-B rows.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv_stem(const int32_t* __restrict__ nbr, int64_t n_out,
+                                                   const float* __restrict__ in, int ld_in,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   const float* __restrict__ residual, int ld_res, int relu,
+                                                   float* __restrict__ out, int ld_out) {
+  static_assert(COUT == 32, "one lane half per row parity");
+  __shared__ float xs[4][64][28];   // pitch 28: the broadcast reads below are conflict-free anyway
+  __shared__ unsigned ms[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  {
+    // every load is unconditional (absent neighbours / rows past the end read row 0 and are masked out):
+    // a per-element "load or not" makes hipcc wait for each of the 27 gathers in turn
+    const bool live = base + lane < n_out;
+    const int64_t o = live ? base + lane : n_out - 1;
+    unsigned m = 0;
+    int32_t src[27];
+    float x[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) src[k] = nbr[o * 27 + k];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      m |= (live && src[k] >= 0 ? 1u : 0u) << k;
+      x[k] = in[(int64_t)(src[k] >= 0 ? src[k] : 0) * ld_in];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) xs[wave][lane][k] = x[k];
+    ms[wave][lane] = m;
+  }
+  __syncthreads();
+  const int co = lane & 31;
+  float wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = w[k * COUT + co];
+  for (int r = lane >> 5; r < 64; r += 2) {
+    const int64_t o = base + r;
+    if (o >= n_out) break;
+    const unsigned m = ms[wave][r];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+      if ((m >> k) & 1u) acc = __fmaf_rn(xs[wave][r][k], wr[k], acc);   // absent offsets are skipped like the oracle
+    const float* res_row = residual ? residual + o * ld_res : nullptr;
+    out[o * ld_out + co] = epilogue(acc, co, scale, shift, res_row, relu);
+  }
+}
+
 
 // Generic VALU path (any cin / cout / alignment; used for cin = 1, the 1 -> 32 stem conv).
 // One thread per (out row, out channel); same canonical fma order.
@@ -624,30 +795,78 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   ProfScope prof("conv", s, flop);
   const bool mfma_ok = (cin % 32 == 0) && (cout % 4 == 0) && (ld_in % 4 == 0) &&
                        aligned16(d_in) && aligned16(d_w);
-  // CS_CONV_LACC=1: the LDS-accumulator kernel with per-offset row compaction (k_conv_lacc).  Bit-identical
-  // results, 1.2 - 1.6x fewer MFMAs, but measured SLOWER than the register-accumulator kernel below on the
-  // bench shapes (DESIGN.md "what was tried on the sparse convolution"): operands fetched per 32-row group
-  // straight from L2 cost more than the LDS-staged 64-row tiles save.  Off by default, kept under test.
-  const bool lacc_on = getenv("CS_CONV_LACC") && getenv("CS_CONV_LACC")[0] == '1';
-  if (mfma_ok && lacc_on && nbr && kvol > 1 && cout % 32 == 0) {
-    const unsigned wgs = (unsigned)ceil_div(ceil_div(n_out, 64), 4);
-    constexpr int LDS2 = 4 * (65 * 64 * 4 + 256), LDS1 = 4 * (65 * 32 * 4 + 256);
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_lacc<2>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-    CS_REQUIRE(attr2 == hipSuccess, CS_ERR_HIP, "cs_conv_fwd: cannot reserve %d bytes of LDS", LDS2);
-    CS_REQUIRE(kvol <= 27, CS_ERR_UNSUPPORTED, "cs_conv_fwd: kernel volume %d", kvol);
-    // 64-column tiles halve the gather traffic, 32-column tiles double the number of waves: the wide form only
-    // when it still gives every SIMD several waves (CS_CONV_NT=1/2 forces one, for experiments)
-    const int force_nt = getenv("CS_CONV_NT") ? atoi(getenv("CS_CONV_NT")) : 0;
-    const bool wide = force_nt ? force_nt == 2 : (int64_t)ceil_div(n_out, 64) * (cout / 64) >= 4096;
-    if (cout % 64 == 0 && wide)
-      hipLaunchKernelGGL((k_conv_lacc<2>), dim3(wgs, (unsigned)(cout / 64)), dim3(256), LDS2, s, nbr, rowlist, kvol,
-                         n_out, d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out,
-                         ld_out);
-    else
-      hipLaunchKernelGGL((k_conv_lacc<1>), dim3(wgs, (unsigned)(cout / 32)), dim3(256), LDS1, s, nbr, rowlist, kvol,
-                         n_out, d_in, ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out,
-                         ld_out);
+  // production path: LDS-DMA staged kernel with per-row-group offset skipping (k_conv_dma); CS_CONV_DMA=0 falls
+  // back to the round-1/2 register-staged kernel (k_conv_mfma), CS_CONV_CFG=<RG><CG><NT> forces one tile shape
+  const bool dma_on = !(getenv("CS_CONV_DMA") && getenv("CS_CONV_DMA")[0] == '0');
+  const int dma_cfg = getenv("CS_CONV_CFG") ? atoi(getenv("CS_CONV_CFG")) : 0;
+  const bool dma_ok = dma_on && mfma_ok && cout % 32 == 0 && kvol <= 27;
+  if (cin == 1 && cout == 32 && kvol == 27 && nbr && n_in >= 1 && dma_on) {
+    hipLaunchKernelGGL((k_conv_stem<32>), dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, s, nbr, n_out, d_in,
+                       ld_in, d_w, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out);
+  } else if (dma_ok) {
+#define CS_DMA_LAUNCH(RG, CG, NT)                                                                              \
+  do {                                                                                                          \
+    const dim3 grid((unsigned)ceil_div(n_out, 32 * RG), (unsigned)(cout / (32 * NT * CG)));                     \
+    if (trace)                                                                                                  \
+      hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, true, true>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_out, d_in, \
+                         ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+    else if (nbr)                                                                                               \
+      hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, true, false>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_out, d_in, \
+                         ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, false, false>), grid, dim3(256), 0, s, nbr, rowlist, kvol, n_out, d_in, \
+                         ld_in, cin, d_w, cout, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+  } while (0)
+    // CS_CONV_TRACE=1: per-wave phase cycles of this launch, summed and printed (diagnostics; synchronises)
+    unsigned long long* trace = nullptr;
+    const size_t trace_n = (size_t)ceil_div(n_out, 32) * (size_t)(cout / 32) * 4 * 8;
+    if (nbr && getenv("CS_CONV_TRACE") && getenv("CS_CONV_TRACE")[0] == '1') {
+      if (hipMalloc(&trace, trace_n * 8) != hipSuccess) trace = nullptr;
+      if (trace) (void)hipMemsetAsync(trace, 0, trace_n * 8, s);
+    }
+    int cfg = dma_cfg;
+    const int64_t t128 = ceil_div(n_out, 128), t64 = ceil_div(n_out, 64);
+    if (cfg == 412 && cout % 64) cfg = 0;
+    if ((cfg == 221) && cout % 64) cfg = 0;
+    if ((cfg == 222 || cfg == 141 || cfg == 414) && cout % 128) cfg = 0;
+    if (!cfg) {
+      // 128-row tiles (4 row groups share a weight slab) while they still give every CU several workgroups,
+      // 64- and 32-row tiles for the coarse levels
+      // the more output columns a wave owns, the more MFMAs each DMA instruction of gathered rows feeds
+      // (NT = 1 / 2 / 4: 16 / 32 / 64 MFMAs per 4 KiB of rows); fewer rows per workgroup where a layer would
+      // otherwise leave CUs without work
+      if (cout % 128 == 0)
+        cfg = t128 * (cout / 128) >= 512 ? 414 : t64 * (cout / 128) >= 256 ? 222 : 141;
+      else if (cout % 64 == 0)
+        cfg = t128 * (cout / 64) >= 512 ? 412 : 221;
+      else
+        cfg = 411;
+    }
+    switch (cfg) {
+      case 412: CS_DMA_LAUNCH(4, 1, 2); break;
+      case 414: CS_DMA_LAUNCH(4, 1, 4); break;
+      case 221: CS_DMA_LAUNCH(2, 2, 1); break;
+      case 222: CS_DMA_LAUNCH(2, 2, 2); break;
+      case 141: CS_DMA_LAUNCH(1, 4, 1); break;
+      default: CS_DMA_LAUNCH(4, 1, 1); break;
+    }
+#undef CS_DMA_LAUNCH
+    if (trace) {
+      std::vector<unsigned long long> h(trace_n);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h.data(), trace, trace_n * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(trace);
+      double tot = 0, vm = 0, wt = 0, cp = 0, nc = 0, na = 0, nw = 0, td = 0, tm = 0;
+      for (size_t i = 0; i + 8 <= trace_n; i += 8)
+        if (h[i]) {
+          tot += h[i]; vm += h[i + 1]; wt += h[i + 2]; cp += h[i + 3]; nc += h[i + 4]; na += h[i + 5]; nw += 1;
+          td += h[i + 6]; tm += h[i + 7];
+        }
+      fprintf(stderr, "[conv trace] cfg %d n_out %lld %d->%d waves %.0f: per wave loop %.0f cyc = vmcnt %.0f + barrier %.0f + body %.0f; "
+              "chunks %.1f active %.1f; per chunk: vmcnt %.0f barrier %.0f body %.0f (dma issue %.0f, reads + mfma %.0f, pointers %.0f)\n",
+              cfg, (long long)n_out, cin, cout, nw, tot / nw, vm / nw, wt / nw, cp / nw, nc / nw, na / nw, vm / nc, wt / nc,
+              cp / nc, td / nc, tm / nc, (cp - td - tm) / nc);
+    }
   } else if (mfma_ok) {
     // 64 x 128 tiles unless that leaves half of the 256 CUs without a workgroup (coarsest level)
     const bool short_tiles = !(getenv("CS_CONV_TILE") && getenv("CS_CONV_TILE")[0] == '0');

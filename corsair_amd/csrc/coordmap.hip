@@ -393,90 +393,27 @@ int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
   return km->num_pairs;
 }
 
-// Tiling order of the convolution kernels: rows grouped by the top ROWKEY_BITS bits of their 27-bit
-// neighbour-presence mask (offsets k = 15..26), so that a 64-row tile can skip the offsets none of
-// its rows has.  Grouping on these 12 bits keeps the conv time of a full 27-bit sort (measured:
-// 7.26 vs 7.19 ms per two 32-cloud forwards, 9.40 unsorted) and is a 3-launch counting sort instead
-// of the ~16 launches of a device radix/merge sort.  The order inside a group is arbitrary: every
-// output row is computed independently, results do not depend on the row order.
-constexpr int ROWKEY_BITS = 12;
-constexpr int ROWKEY_BINS = 1 << ROWKEY_BITS;
-// workgroup-local histogram in LDS, one global atomic per (workgroup, non-empty bin)
-constexpr int ROWKEY_PER = 4;  // rows per thread
+// Tiling order of the convolution kernels: output rows sorted by the Gray-code RANK of their 27-bit
+// neighbour-presence mask (rows with the same mask are adjacent; neighbours in the order differ in few
+// offsets).  A 32-row group of k_conv_dma then executes only 1.2 - 1.4x the MFMAs its rows need, because
+// it skips every offset none of its rows has (measured on the stress clouds, executed / useful per 32-row
+// group at strides 1 / 2 / 4: Gray rank 1.41 / 1.19 / 1.28, plain numeric order 1.48 / 1.20 / 1.29, the
+// 12-bit grouping of rounds 1-2 2.05 / 1.59 / 1.52).  The order inside equal keys is the radix sort's
+// (stable: row order); every output row is computed independently, results do not depend on the order.
 __global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
-                                                  uint32_t* __restrict__ key, int32_t* __restrict__ hist) {
-  __shared__ int32_t lh[ROWKEY_BINS];
-  for (int i = threadIdx.x; i < ROWKEY_BINS; i += 256) lh[i] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * (256 * ROWKEY_PER);
-#pragma unroll
-  for (int j = 0; j < ROWKEY_PER; ++j) {
-    const int64_t o = base + j * 256 + threadIdx.x;
-    if (o < n_out) {
-      uint32_t m = 0;
-      for (int k = 0; k < kvol; ++k) m |= (nbr[o * kvol + k] >= 0 ? 1u : 0u) << k;
-      const uint32_t kx = m >> (27 - ROWKEY_BITS);
-      key[o] = kx;
-      atomicAdd(&lh[kx], 1);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ROWKEY_BINS; i += 256)
-    if (lh[i]) atomicAdd(&hist[i], lh[i]);
-}
-// one workgroup: exclusive scan of the bin counts -> first slot of every bin (in place)
-__global__ __launch_bounds__(1024) void k_row_bins(int32_t* __restrict__ hist) {
-  __shared__ int32_t part[1024];
-  const int t = threadIdx.x;
-  constexpr int PER = ROWKEY_BINS / 1024;
-  int32_t v[PER], sum = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    v[j] = hist[t * PER + j];
-    sum += v[j];
-  }
-  part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int32_t add = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += add;
-    __syncthreads();
-  }
-  int32_t run = part[t] - sum;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    hist[t * PER + j] = run;
-    run += v[j];
-  }
-}
-// rank inside the workgroup from LDS atomics, one global reservation per (workgroup, non-empty bin)
-__global__ __launch_bounds__(256) void k_row_scatter(const uint32_t* __restrict__ key, int64_t n_out,
-                                                     int32_t* __restrict__ cursor,
-                                                     int32_t* __restrict__ rowlist) {
-  __shared__ int32_t lh[ROWKEY_BINS];
-  for (int i = threadIdx.x; i < ROWKEY_BINS; i += 256) lh[i] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * (256 * ROWKEY_PER);
-  uint32_t kx[ROWKEY_PER];
-  int32_t rank[ROWKEY_PER];
-#pragma unroll
-  for (int j = 0; j < ROWKEY_PER; ++j) {
-    const int64_t o = base + j * 256 + threadIdx.x;
-    kx[j] = 0;
-    rank[j] = -1;
-    if (o < n_out) {
-      kx[j] = key[o];
-      rank[j] = atomicAdd(&lh[kx[j]], 1);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ROWKEY_BINS; i += 256)
-    if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);  // count -> first slot of this workgroup's run
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < ROWKEY_PER; ++j)
-    if (rank[j] >= 0) rowlist[lh[kx[j]] + rank[j]] = (int32_t)(base + j * 256 + threadIdx.x);
+                                                  uint32_t* __restrict__ key, int32_t* __restrict__ row) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  uint32_t m = 0;
+  for (int k = 0; k < kvol; ++k) m |= (nbr[o * kvol + k] >= 0 ? 1u : 0u) << k;
+  // inverse Gray code: r with r ^ (r >> 1) == m
+  m ^= m >> 1;
+  m ^= m >> 2;
+  m ^= m >> 4;
+  m ^= m >> 8;
+  m ^= m >> 16;
+  key[o] = m;
+  row[o] = (int32_t)o;
 }
 
 // export helpers: element t = k * n_out + o of the k-major view
@@ -804,23 +741,26 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     set_error("cs_kernelmap_build: %s", hipGetErrorString(e));
     return CS_ERR_HIP;
   }
-  // tiling order for the convolution kernels: rows grouped by presence-mask key (k_row_keys)
+  // tiling order for the convolution kernels: rows sorted by the Gray rank of their presence mask
   if (km->kvol == 27 && km->n_out > 0) {
     const int64_t n = km->n_out;
     km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
-    PoolBuf<uint32_t> key(n);
-    PoolBuf<int32_t> bins(ROWKEY_BINS);
-    if (!km->d_rowlist || !key.p || !bins.p) {
+    PoolBuf<uint32_t> key(n), key_sorted(n);
+    PoolBuf<int32_t> row(n);
+    size_t tmp_bytes = 0;
+    hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist,
+                                                       (int)n, 0, 27, s);
+    PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    if (!km->d_rowlist || !key.p || !key_sorted.p || !row.p || !tmp.p) {
       cs_kernelmap_free(km);
       set_error("cs_kernelmap_build: row list allocation failed");
       return CS_ERR_HIP;
     }
-    hipError_t e2 = hipMemsetAsync(bins.p, 0, sizeof(int32_t) * ROWKEY_BINS, s);
-    hipLaunchKernelGGL(k_row_keys, dim3((unsigned)ceil_div(n, 256 * ROWKEY_PER)), dim3(256), 0, s,
-                       km->d_nbr, n, km->kvol, key.p, bins.p);
-    hipLaunchKernelGGL(k_row_bins, dim3(1), dim3(1024), 0, s, bins.p);
-    hipLaunchKernelGGL(k_row_scatter, dim3((unsigned)ceil_div(n, 256 * ROWKEY_PER)), dim3(256), 0, s, key.p,
-                       n, bins.p, km->d_rowlist);
+    hipLaunchKernelGGL(k_row_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, km->d_nbr, n, km->kvol, key.p,
+                       row.p);
+    if (e2 == hipSuccess)
+      e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist, (int)n, 0,
+                                              27, s);
     if (e2 == hipSuccess) e2 = hipGetLastError();
     // no synchronisation: the scratch returns to this thread's stream-ordered cache
     if (e2 != hipSuccess) {

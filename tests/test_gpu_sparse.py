@@ -66,22 +66,31 @@ def test_conv_bit_exact(gpu, oracle_native, cin, cout):
     assert got.shape == (n, cout) and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("nt", ["1", "2"])
-def test_conv_lds_accumulator_kernel_bit_exact(gpu, oracle_native, monkeypatch, nt):
-    """CS_CONV_LACC=1: the experimental k_conv_lacc (accumulators in LDS, rows compacted per offset, operands
-    straight from L2 through v_permlane32_swap) computes the same fma chains: whole network bit-exact."""
+@pytest.mark.parametrize("cfg", ["411", "412", "414", "221", "222", "141", "old"])
+def test_conv_every_tile_shape_bit_exact(gpu, oracle_native, monkeypatch, cfg):
+    """Every tile shape of the LDS-DMA kernel (CS_CONV_CFG=<row groups><column groups><32-column
+    accumulators per wave>; shapes a layer's Cout does not allow fall back to the default choice) and
+    the round-1/2 register-staged kernel (CS_CONV_DMA=0) compute the same fma chains: the whole network,
+    1x1 / strided / transposed layers included, is bit-exact against the oracle.  The batch has a ragged
+    last tile at every level and an empty sample."""
     from corsair_amd import engine, synth
     from oracle import resunet as oref
 
-    monkeypatch.setenv("CS_CONV_LACC", "1")
-    monkeypatch.setenv("CS_CONV_NT", nt)
+    if cfg == "old":
+        monkeypatch.setenv("CS_CONV_DMA", "0")
+    else:
+        monkeypatch.setenv("CS_CONV_CFG", cfg)
     coords, feats, _, _ = make_batch([5, 6, 7], n_points=5000)
+    coords[coords[:, 0] == 2, 0] = 3          # sample 2 is empty
     sd, emb = synth.make_state_dicts(31)
     eng = engine.ResUNetEngine(sd, emb, device=gpu)
     out, feat, maps = eng.forward(torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu))
-    want_out, want_feat, _ = oref.resunet_forward(sd, coords, feats)
+    g = eng.embed(feat, maps, 4)
+    want_out, want_feat, omaps = oref.resunet_forward(sd, coords, feats)
+    want_g = oref.embedding_forward(emb, want_feat, omaps["c8"][:, 0], 4)
     assert np.array_equal(out.cpu().numpy(), want_out)
     assert np.array_equal(feat.cpu().numpy(), want_feat)
+    assert np.array_equal(g[[0, 1, 3]].cpu().numpy(), want_g[[0, 1, 3]])
 
 
 def test_resunet_forward_bit_exact(gpu, oracle_native):
