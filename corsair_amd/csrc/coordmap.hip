@@ -416,6 +416,31 @@ __global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nb
   row[o] = (int32_t)o;
 }
 
+// the neighbour table in tiling order + the offsets every 32-row group of that order uses (one thread per
+// table element; the group masks come from the sorted keys: mask = Gray code of the rank)
+__global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist,
+                                                       const uint32_t* __restrict__ key_sorted, int64_t n_out, int kvol,
+                                                       int32_t* __restrict__ nbr_sorted, uint32_t* __restrict__ gmask,
+                                                       int64_t n_groups_padded) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n_out * kvol) {
+    const int64_t t = e / kvol;
+    const int k = (int)(e - t * kvol);
+    nbr_sorted[e] = nbr[(int64_t)rowlist[t] * kvol + k];
+  }
+  if (e < n_groups_padded) {
+    uint32_t m = 0;
+    for (int r = 0; r < 32; ++r) {
+      const int64_t t = e * 32 + r;
+      if (t < n_out) {
+        const uint32_t rank = key_sorted[t];
+        m |= rank ^ (rank >> 1);
+      }
+    }
+    gmask[e] = m;
+  }
+}
+
 // export helpers: element t = k * n_out + o of the k-major view
 __global__ void k_export_flag(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
                               int32_t* flag) {
@@ -761,6 +786,16 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     if (e2 == hipSuccess)
       e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist, (int)n, 0,
                                               27, s);
+    const int64_t n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
+    km->d_nbr_sorted = (int32_t*)pool_alloc((size_t)n * km->kvol * sizeof(int32_t));
+    km->d_gmask = (uint32_t*)pool_alloc((size_t)n_groups * sizeof(uint32_t));
+    if (!km->d_nbr_sorted || !km->d_gmask) {
+      cs_kernelmap_free(km);
+      set_error("cs_kernelmap_build: sorted table allocation failed");
+      return CS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_sorted_tables, dim3((unsigned)ceil_div(n * km->kvol, 256)), dim3(256), 0, s, km->d_nbr,
+                       km->d_rowlist, key_sorted.p, n, km->kvol, km->d_nbr_sorted, km->d_gmask, n_groups);
     if (e2 == hipSuccess) e2 = hipGetLastError();
     // no synchronisation: the scratch returns to this thread's stream-ordered cache
     if (e2 != hipSuccess) {
@@ -807,6 +842,8 @@ void cs_kernelmap_free(cs_kernelmap* km) {
   if (!km) return;
   pool_free(km->d_nbr);
   pool_free(km->d_rowlist);
+  pool_free(km->d_nbr_sorted);
+  pool_free(km->d_gmask);
   if (km->cnt_ready) {
     (void)hipEventSynchronize(km->cnt_ready);  // the slot must not be recycled under a pending copy
     (void)hipEventDestroy(km->cnt_ready);
