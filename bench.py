@@ -44,6 +44,12 @@ F32_PEAK_TFLOPS = 157.3   # MI355X f32: matrix (v_mfma_f32_32x32x2_f32) == vecto
 F64_PEAK_TFLOPS = 78.6
 F16_PEAK_TFLOPS = 2516.6  # dense f16/bf16 MFMA: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (16x the f32 matrix rate)
 BATCH = 32
+# the full 32-query C1 shape on the CPU port (`--cpu-sample 32 --cpu-problems 100000`), measured once per round
+# on a GPU box's host cores and printed next to the bounded sample of every run
+FULL_SHAPE_CPU = {
+    "chair": {"value": 0.152, "unit": "queries/s", "cores": 16, "seconds": 210.5, "date": "round 2", "commit": "d39958b",
+              "file": "profiles/r2l_chair_cpu32_line.json"},
+}
 
 # label -> count; table: histogram of the reference's configs/04379243_scan2cad_rot_sym_label.txt
 # (SURVEY 2 #28), chair: configs/03001627_scan2cad_rot_sym_label.txt
@@ -62,6 +68,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=("chair", "table", "stress"), default="chair")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="N > 1: if the RCCL communicator does not come up, run the exchange over gloo instead of "
+                         "failing (every rank must agree; the JSON line then says dist.backend = gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6,
                     help="most queries in the CPU baseline sample (SURVEY 8d's full shape: 32)")
@@ -80,6 +89,29 @@ def parse():
     return ap.parse_args()
 
 
+def visible_device_count():
+    """GPUs this process may use, WITHOUT touching HIP (the launcher parent must stay a plain process: its
+    ranks start as a child, never by exec): the KFD topology lists one node per device, *_VISIBLE_DEVICES
+    narrows it.  Falls back to torch only if sysfs is unreadable."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        n = 0
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:      # CPU nodes have no SIMDs
+                n += 1
+        return n
+    except OSError:
+        import torch
+
+        return torch.cuda.device_count()
+
+
 def maybe_self_launch(args):
     """`python bench.py --gpus N` without torchrun: start the N ranks as a CHILD process (never an exec,
     and before this process has made any HIP call) and leave with its return code."""
@@ -92,10 +124,8 @@ def maybe_self_launch(args):
         return
     if args.gpus <= 1:
         return
-    import torch  # device_count() does not create a HIP context
-
     env = dict(os.environ)
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_device_count()
     if n_dev < args.gpus and "CORSAIR_DIST_BACKEND" not in env:
         # rehearsal on a box with fewer devices than ranks: ranks share devices, RCCL cannot (it needs
         # one device per rank), so the exchange runs over gloo; the JSON line says so
@@ -136,17 +166,35 @@ class Ctx:
             import torch.distributed as dist
 
             if self.backend == "nccl":
+                # RCCL failing to come up is an ERROR (exit non-zero with the reason): a scaling run that quietly
+                # measured gloo would be worse than none.  --allow-gloo turns it into a gloo run, and then every
+                # rank takes the same decision: the verdicts are exchanged through torchrun's store first.
+                err = None
                 try:
                     dist.init_process_group("nccl", device_id=self.dev)
                     probe = torch.ones(1, device=self.dev)
                     dist.all_reduce(probe)              # first collective: communicator really comes up
                     torch.cuda.synchronize()
-                except Exception as e:                  # RCCL unusable on this node: the exchange is setup-only,
-                    sys.stderr.write("[bench] rank %d: RCCL init failed (%s); falling back to gloo\n" % (self.rank, e))
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                    self.backend = "gloo"
-                    dist.init_process_group("gloo")
+                except Exception as e:
+                    err = e
+                if err is not None and not args.allow_gloo:
+                    sys.stderr.write("[bench] rank %d: RCCL init failed: %s\n[bench] refusing to fall back to gloo "
+                                     "silently (pass --allow-gloo to measure over gloo)\n" % (self.rank, err))
+                    sys.exit(3)
+                if args.allow_gloo:
+                    from datetime import timedelta
+
+                    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, self.world,
+                                          self.rank == 0, timeout=timedelta(seconds=120))
+                    store.set("rccl_ok_%d" % self.rank, "0" if err is not None else "1")
+                    all_ok = all(store.get("rccl_ok_%d" % r) == b"1" for r in range(self.world))
+                    if not all_ok:
+                        sys.stderr.write("[bench] rank %d: RCCL unusable on at least one rank (%s); --allow-gloo: "
+                                         "all ranks switch to gloo\n" % (self.rank, err))
+                        if dist.is_initialized():
+                            dist.destroy_process_group()
+                        self.backend = "gloo"
+                        dist.init_process_group("gloo")
             else:
                 dist.init_process_group(self.backend)
             self.dist = dist
@@ -388,8 +436,12 @@ class RegistrationWorkload:
             nprob += 1 + len(R.part_configs(4 if sym[c] >= 2 else 2, int(sym[c])))
         total = time.time() - t0
         t_reg = total - t_embed - t_ret
-        per_query = (t_embed + t_ret) / n + t_reg / done
-        return {"value": 1.0 / per_query, "unit": "queries/s", "cores": native.num_threads(), "kind": "port",
+        per_query = (t_embed + t_ret) / n + t_reg / max(done, 1)
+        return {"value": 1.0 / per_query, "unit": "queries/s", "cores": native.num_threads(),
+                "cores_visible": native.cores_visible(), "cgroup_cpu_quota": native.cgroup_cpu_quota(),
+                "cores_note": "threads = the box's CPU share (min of affinity, cgroup quota, ORACLE_THREADS default 16: a "
+                              "one-GPU box of the pool is entitled to 16 of the CPUs it can see)", "kind": "port",
+                "full_shape": FULL_SHAPE_CPU.get("chair" if self.C == 652 else "table"),
                 "sample": "queries of the first timed step against a %d-item catalog subset (SURVEY 8d C1 shape "
                           "is 32 x 64; the per-query cost does not depend on the subset size beyond the "
                           "retrieval term, so the rate extrapolates linearly): oracle embed of %d queries "
@@ -699,7 +751,7 @@ def main():
             out["metric"] = "stress queries/sec (batch-64 forward + top-10 share), configs[4]"
             out["kernel_tflops"] = {k: round(fam[k]["flop"] / max(fam[k]["ms"], 1e-9) / 1e9, 2)
                                     for k in ("conv", "topk")}
-            out["est_full_job_s"] = 100000.0 * ctx.world / out["value"]  # 100k clouds + 10^6 x 10^6 top-10
+            out["est_full_job_s"] = 100000.0 / out["value"]  # 100k clouds + 10^6 x 10^6 top-10 (value = all ranks)
         if ctx.world > 1:
             out["dist"] = {"backend": "rccl" if ctx.backend == "nccl" else ctx.backend,
                            "devices_visible": ctx.n_devices,
@@ -712,8 +764,7 @@ def main():
                 "ms_per_step": overlap[0] / args.steps * 1e3, "identical_results": bool(overlap[1]),
                 "note": "same K batches again with three host threads x three HIP streams (python bench.py --pipeline 3); "
                         "not the contract number (the live per-launch times of `roofline` would include the "
-                        "neighbours' kernels).  32 steps measure 1 087 -> 1 143 / 1 194 / 1 180 queries/s at depth "
-                        "1 -> 2 / 3 / 4 on one box"}
+                        "neighbours' kernels)"}
         if ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out))

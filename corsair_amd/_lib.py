@@ -64,6 +64,9 @@ def _declare(lib):
         "cs_symcut_fit": (c_int, [vp, c_int, vp, POINTER(c_int64), c_int, vp, c_int,
                                   POINTER(c_int32), c_int, c_int, c_int, c_uint64, vp, vp, vp, vp, vp]),
         "cs_symcut_labels": (c_int, [vp, POINTER(c_int64), c_int, POINTER(c_int32), vp, vp, vp]),
+        "cs_partition_by_label": (c_int, [vp, vp, c_int, vp, vp]),
+        "cs_cfg_bad": (c_int, [vp, c_int, vp, c_int, vp, vp]),
+        "cs_corr_assemble": (c_int, [vp, vp, vp, vp, c_int, vp, c_int, c_int64, vp, vp, vp]),
         "cs_prof_enable": (None, [c_int]),
         "cs_prof_reset": (None, []),
         "cs_prof_get": (c_int, [c_char_p, POINTER(c_double), POINTER(c_int64)]),

@@ -321,6 +321,39 @@ def ransac_batch(src, tgt, offsets, max_corr, ransac_n=10, max_iter=100000, conf
     return T, inl, rmse, iters
 
 
+def partition_by_label(label, d_off, n_cloud):
+    """Rows of every cloud stably partitioned by part label (split_corr's part order).  d_off: int64 device
+    tensor [n_cloud + 1].  Returns int64 [N] global row indices."""
+    label = _dev(label, torch.int32, "labels").contiguous()
+    order = torch.empty(label.shape[0], dtype=torch.int64, device=label.device)
+    check(_lib.load().cs_partition_by_label(ptr(label), ptr(d_off), n_cloud, ptr(order), stream_ptr()))
+    return order
+
+
+def cfg_bad(nn, d_first, n_cfg):
+    """int32 [n_cfg]: 1 where rows [first[j], first[j+1]) of the neighbour lists hold a negative entry."""
+    nn = _dev(nn, torch.int32, "neighbour lists").contiguous()
+    bad = torch.empty(n_cfg, dtype=torch.int32, device=nn.device)
+    check(_lib.load().cs_cfg_bad(ptr(nn), nn.shape[1], ptr(d_first), n_cfg, ptr(bad), stream_ptr()))
+    return bad
+
+
+def corr_assemble(xyz0, xyz1, rows, nn, desc, total, max_len):
+    """Correspondence lists of the configurations desc (host int64 [n_cfg, 5] = q_first, n_first, t_first, len,
+    out_first): returns (src f32 [total * k, 3], tgt f32 [total * k, 3])."""
+    xyz0 = _dev(xyz0, torch.float32, "query xyz").contiguous()
+    xyz1 = _dev(xyz1, torch.float32, "CAD xyz").contiguous()
+    nn = _dev(nn, torch.int32, "neighbour lists").contiguous()
+    k = nn.shape[1]
+    dev = xyz0.device
+    src = torch.empty((total * k, 3), dtype=torch.float32, device=dev)
+    tgt = torch.empty((total * k, 3), dtype=torch.float32, device=dev)
+    d_desc = torch.from_numpy(np.ascontiguousarray(desc, dtype=np.int64)).to(dev, non_blocking=True)
+    check(_lib.load().cs_corr_assemble(ptr(xyz0), ptr(xyz1), ptr(rows) if rows is not None else None, ptr(nn), k,
+                                       ptr(d_desc), len(desc), int(max_len), ptr(src), ptr(tgt), stream_ptr()))
+    return src, tgt
+
+
 def symcut_fit(feat, xyz, offsets, anchors, Ks, n_nn=50, n_init=10, max_iter=300, seed=0):
     """anchors int32 [n_cloud, n_anchor] device; Ks host list.  Returns centers f64 [c,a,4,3],
     counts int32 [c,a,4], min centre distance f64 [c,a], max error f64 [c,a]."""

@@ -401,8 +401,13 @@ int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
 // 12-bit grouping of rounds 1-2 2.05 / 1.59 / 1.52).  The order inside equal keys is the radix sort's
 // (stable: row order); every output row is computed independently, results do not depend on the order.
 __global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
-                                                  uint32_t* __restrict__ key, int32_t* __restrict__ row) {
+                                                  uint32_t* __restrict__ key, int32_t* __restrict__ row,
+                                                  const unsigned long long* __restrict__ d_cnt,
+                                                  unsigned long long* host_cnt) {
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the pair count of the build kernels in front of this one goes to its page-locked slot from here (a
+  // device -> host copy of 8 bytes was one blit-kernel launch per map)
+  if (o == 0 && host_cnt) __hip_atomic_store(host_cnt, *d_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (o >= n_out) return;
   uint32_t m = 0;
   for (int k = 0; k < kvol; ++k) m |= (nbr[o * kvol + k] >= 0 ? 1u : 0u) << k;
@@ -692,7 +697,7 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     set_error("cs_kernelmap_build: allocation failed");
     return CS_ERR_HIP;
   }
-  hipError_t e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s);
+  hipError_t e = hipSuccess;
   // LDS path: per-sample hash tables (see k_build_nbr_lds), the flagged samples through the global
   // table right behind it; otherwise the global table for everything.  No host decision in between:
   // the pair count travels to a page-locked slot and is read when somebody asks (kernelmap_pairs).
@@ -743,11 +748,13 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     }
   }
   if (e == hipSuccess && total > 0 && !used_lds) {
+    e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s);   // (the LDS path keeps its counter in `fb`)
     hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        out->d_coords, km->n_out, km->kvol, step, sign, in->d_keys, in->d_vals,
                        in->capacity - 1, km->d_nbr, cnt.p, (const int*)nullptr);
     e = hipGetLastError();
   }
+  unsigned long long* cnt_host_dev = nullptr;
   if (e == hipSuccess) {
     if (total == 0) {
       km->num_pairs = 0;
@@ -755,7 +762,12 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
       km->h_cnt = count_slot_acquire(&km->cnt_slot);
       if (!km->h_cnt || hipEventCreateWithFlags(&km->cnt_ready, hipEventDisableTiming) != hipSuccess) {
         e = hipErrorOutOfMemory;
-      } else {
+      } else if (km->kvol == 27) {
+        // the row-key kernel below writes the count into the page-locked slot itself (no copy launch)
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&cnt_host_dev), km->h_cnt, 0) != hipSuccess)
+          cnt_host_dev = nullptr;
+      }
+      if (e == hipSuccess && !cnt_host_dev) {
         e = hipMemcpyAsync(km->h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipEventRecord(km->cnt_ready, s);
       }
@@ -782,7 +794,8 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
       return CS_ERR_HIP;
     }
     hipLaunchKernelGGL(k_row_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, km->d_nbr, n, km->kvol, key.p,
-                       row.p);
+                       row.p, d_cnt, cnt_host_dev);
+    if (cnt_host_dev && hipEventRecord(km->cnt_ready, s) != hipSuccess) e2 = hipErrorUnknown;
     if (e2 == hipSuccess)
       e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist, (int)n, 0,
                                               27, s);

@@ -159,19 +159,30 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
 // hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
 // RN = ransac_n when it is known at compile time (10: the reference's value; the sampled pairs then stay
 // in registers between the centroid and the covariance pass), 0 = read it from the argument
+// Placement table of a round (problem of XCD x, slot i) as a kernel ARGUMENT: the host builds it per round, a
+// device copy of it was one hipMemcpyAsync (a blit-kernel launch) per round.  Rounds with more than XCD_SLOTS
+// problems per XCD fall back to the device table (xcd_ptr != nullptr).
+constexpr int XCD_SLOTS = 64;
+struct XcdTab {
+  int32_t v[8 * XCD_SLOTS];
+};
+__device__ __forceinline__ int xcd_problem(const int32_t* __restrict__ xcd_ptr, const XcdTab& tab, int i) {
+  return xcd_ptr ? xcd_ptr[i] : tab.v[i];
+}
+
 template <int RN>
 __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     const float4* __restrict__ pair32, int it0,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed,
-                                                    const int32_t* __restrict__ xcd_prob, int slots,
-                                                    int tiles, double* __restrict__ hyp) {
+                                                    const int32_t* __restrict__ xcd_prob, const XcdTab xcd_tab,
+                                                    int slots, int tiles, double* __restrict__ hyp) {
   // 1-D grid dealt round-robin to the XCDs: XCD x samples only the problems xcd_prob[x][.], whose
   // correspondences then stay in that XCD's L2 (the sampling is a random gather of 24-B rows)
   const int xcd = blockIdx.x & 7;
   const int item = blockIdx.x >> 3;
   const int slot = item / tiles;
-  const int p = xcd_prob[xcd * slots + slot];
+  const int p = xcd_problem(xcd_prob, xcd_tab, xcd * slots + slot);
   if (p < 0) return;
   const int h = (item - slot * tiles) * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
@@ -553,10 +564,14 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 // a zero row: every pair counts, it always survives to the exact kernel.
 __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
                                const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
-                               double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h) {
+                               double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
+                               int32_t* __restrict__ cnt_zero) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
+  // the prefilter behind this kernel adds the partial counts of its pair-range splits with atomics: the
+  // counters of this round are cleared here (a hipMemset2DAsync per round before)
+  if (cnt_zero) cnt_zero[(int64_t)p * bmax + h] = 0;
   const RansacProb pr = prob_view(probs, p);
   if (pr.done || it0 + h >= pr.est_k) return;
   const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
@@ -638,7 +653,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
                                                           const float* __restrict__ c_h, int it0,
                                                           int bcount, int bmax, int splits,
                                                           const int32_t* __restrict__ xcd_prob,
-                                                          int slots, int tiles,
+                                                          const XcdTab xcd_tab, int slots, int tiles,
                                                           int32_t* __restrict__ cnt_up,
                                                           unsigned long long* __restrict__ trace) {
   const unsigned long long t_start = trace ? wall_clock64() : 0ULL;
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   const int item = blockIdx.x >> 3;
   const int slot = item / (tiles * splits);
   const int inner = item - slot * (tiles * splits);
-  const int p = xcd_prob[xcd * slots + slot];
+  const int p = xcd_problem(xcd_prob, xcd_tab, xcd * slots + slot);
   if (p < 0) return;
   const int tile = inner / splits;
   const int split = inner - tile * splits;
@@ -1076,9 +1091,13 @@ __global__ __launch_bounds__(256) void k_ransac_err(const RansacProb* __restrict
 __global__ void k_ransac_scan2(RansacProb* probs, int n_prob, const double* __restrict__ hyp,
                                const int32_t* __restrict__ cand,
                                const unsigned long long* __restrict__ cand_err, int by_h, int it0,
-                               int bmax) {
+                               int bmax, int32_t* __restrict__ next_nsurv, int* __restrict__ next_nactive) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_prob) return;
+  // last kernel of a round: clear the survivor / activity counters the NEXT round accumulates into (the other
+  // parity's: this round's are still to be copied to the host) -- a hipMemsetAsync per round before
+  next_nsurv[p] = 0;
+  if (p == 0) *next_nactive = 0;
   RansacProb pr = probs[p];
   if (pr.n_cand <= 0) return;
   bool changed = false;
@@ -1215,14 +1234,16 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 256;
   const int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : first_chunk;
   // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
-  // [RansacProb x n_prob | n_surv int32 x n_prob (padded to 8 B) | n_active int32]
+  // [RansacProb x n_prob | 2 x { n_surv int32 x n_prob (padded to 8 B) | n_active int32 (8 B) }]: the counters
+  // exist once per round parity, k_ransac_scan2 clears the set of the next round
   const size_t st_probs = sizeof(RansacProb) * (size_t)n_prob;
   const size_t st_surv = ((sizeof(int32_t) * (size_t)n_prob + 7) / 8) * 8;
-  const size_t st_bytes = st_probs + st_surv + 8;
+  const size_t st_cnt = st_surv + 8;
+  const size_t st_bytes = st_probs + 2 * st_cnt;
   PoolBuf<char> state(st_bytes);
   RansacProb* const d_probs = reinterpret_cast<RansacProb*>(state.p);
-  int32_t* const d_nsurv = reinterpret_cast<int32_t*>(state.p + st_probs);
-  int* const d_nactive = reinterpret_cast<int*>(state.p + st_probs + st_surv);
+  auto nsurv_of = [&](int par) { return reinterpret_cast<int32_t*>(state.p + st_probs + par * st_cnt); };
+  auto nactive_of = [&](int par) { return reinterpret_cast<int*>(state.p + st_probs + par * st_cnt + st_surv); };
   char* const h_state = pinned_scratch(st_bytes);
   CS_REQUIRE(state.p && h_state, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   PoolBuf<float> pk((size_t)tot1 * 6);
@@ -1251,8 +1272,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // placement tables, one per round parity (8 x n_prob entries each)
   PoolBuf<int32_t> xcd_buf((size_t)16 * n_prob);
   CS_REQUIRE(xcd_buf.p, CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
-  CS_HIP_CHECK(hipMemcpyAsync(d_probs, hp.data(), sizeof(RansacProb) * n_prob,
-                              hipMemcpyHostToDevice, s));
+  {
+    // problems + zeroed counters in one upload (h_state is page-locked and not read before the first round ends)
+    memset(h_state, 0, st_bytes);
+    memcpy(h_state, hp.data(), st_probs);
+    CS_HIP_CHECK(hipMemcpyAsync(state.p, h_state, st_bytes, hipMemcpyHostToDevice, s));
+  }
   if (total > 0) {
     hipLaunchKernelGGL(k_ransac_pack, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        d_src, d_tgt, total, pk.p, pair32.p);
@@ -1346,18 +1371,24 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     tab.assign((size_t)8 * pslots, -1);
     for (int x = 0; x < 8; ++x)
       for (size_t i = 0; i < lists[x].size(); ++i) tab[(size_t)x * pslots + i] = lists[x][i];
-    int32_t* xcd_prob = xcd_buf.p + (size_t)par * 8 * n_prob;
-    (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, st);
+    int32_t* xcd_prob = nullptr;
+    XcdTab xtab;
+    if (pslots <= XCD_SLOTS) {
+      memcpy(xtab.v, tab.data(), sizeof(int32_t) * 8 * pslots);
+    } else {
+      xcd_prob = xcd_buf.p + (size_t)par * 8 * n_prob;
+      (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, st);
+    }
     double* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
     {
       ProfScope prof("ransac_hyp", st);
       const int htiles = (b + 255) / 256;
       if (ransac_n == 10)
         hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
       else
         hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, pslots, htiles, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
     }
     if (f.pf) {
       _Float16* A16_r = A16.p + (size_t)par * n_prob * bmax * PF_K;
@@ -1371,14 +1402,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (psplits > 16) psplits = 16;
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, st, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r);
-      if (psplits > 1)
-        (void)hipMemset2DAsync(cnt_up_r, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b, n_prob, st);
+                         0, st, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r,
+                         psplits > 1 ? cnt_up_r : (int32_t*)nullptr);
       {
         ProfScope prof("ransac_pre", st);  // work units are added by the back half (state known there)
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
         hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
-                           A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, pslots, ptiles, cnt_up_r,
+                           A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
                            (trace_it0 == it0) ? trace.p : nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
@@ -1409,7 +1439,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (splits < 1) splits = 1;
     if (splits > 16) splits = 16;
     while (splits > 1 && m_max / splits < 4 * RC_CHUNK) --splits;
-    CS_HIP_CHECK(hipMemsetAsync(d_nsurv, 0, st_surv + 8, s));  // survivor counts and n_active
+    int32_t* const d_nsurv = nsurv_of(cur.par);   // cleared by the previous round's k_ransac_scan2 (or the upload)
+    int* const d_nactive = nactive_of(cur.par);
     // algorithmic work of this chunk (hp is the state before it): 30 FLOP per (evaluated hypothesis,
     // correspondence) (transform 18 + squared distance 8 + compare/accumulate) -- for the
     // exact count and for the prefilter alike (its matrix pipe executes 64 per pair: the 32
@@ -1475,7 +1506,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
                          tot1, hyp_r, bmax, cand.p, thr2, scale, cand_err.p);
     hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       d_probs, n_prob, hyp_r, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax);
+                       d_probs, n_prob, hyp_r, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax, nsurv_of(cur.par ^ 1),
+                       nactive_of(cur.par ^ 1));
     CS_LAUNCH_CHECK();
     // the per-problem state (est_k, done), the survivor counts and the activity counter come back in
     // one copy behind a synchronisation the chunk loop needs anyway
@@ -1500,9 +1532,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     }
     CS_HIP_CHECK(hipEventSynchronize(round_done.e));
     memcpy(hp.data(), h_state, st_probs);
-    memcpy(h_surv.data(), h_state + st_probs, sizeof(int32_t) * n_prob);
+    memcpy(h_surv.data(), h_state + st_probs + cur.par * st_cnt, sizeof(int32_t) * n_prob);
     int h_active = 0;
-    memcpy(&h_active, h_state + st_probs + st_surv, sizeof(int));
+    memcpy(&h_active, h_state + st_probs + cur.par * st_cnt + st_surv, sizeof(int));
     if (pf) {
       max_surv_prev = 0;
       for (int p = 0; p < n_prob; ++p)

@@ -161,22 +161,18 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
 
     # ---- 1. vanilla correspondences (find_kcorr, utils/eval_pose.py:48-79) -----------------
     nn = B.knn_feat(baseF, off0, posF, off1, k)                     # [N0, k] local CAD rows
-    # (output_size given: repeat_interleave with tensor repeats otherwise reads the total back to the
-    # host, a synchronisation in the middle of the launch sequence)
-    toff_rows = torch.repeat_interleave(
-        torch.tensor(off1[:-1], device=dev, dtype=torch.int64),
-        torch.tensor(n0, device=dev, dtype=torch.int64), output_size=off0[-1])  # CAD segment start per query row
-    tgt_rows = (nn.to(torch.int64) + toff_rows[:, None]).reshape(-1)
-    src_rows = torch.arange(off0[-1], device=dev, dtype=torch.int64).repeat_interleave(k)
-    prob_src = [src_rows]
-    prob_tgt = [tgt_rows]
+    # correspondence lists straight from the neighbour lists (one launch; rounds 1-2 built index tensors with
+    # repeat_interleave / arange / gathers): pair p = query rows off0[p]:off0[p+1] against the CAD cloud at off1[p]
+    desc_v = np.asarray([[off0[p], off0[p], off1[p], n0[p], off0[p]] for p in range(P)], dtype=np.int64).reshape(P, 5)
+    v_src, v_tgt = B.corr_assemble(xyz0, xyz1, None, nn, desc_v, off0[-1], max(n0) if P else 0)
+    corr_src = [v_src]
+    corr_tgt = [v_tgt]
     prob_len = [n0[p] * k for p in range(P)]
     prob_pair = list(range(P))
     prob_cfg = [None] * P
     ok = np.zeros(P, dtype=bool)
     vanilla = None
     if use_symmetry and dev.type == "cuda" and os.environ.get("CORSAIR_SPLIT_RANSAC", "1") != "0":
-        v_src, v_tgt = xyz0[src_rows], xyz1[tgt_rows]
         v_offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
         for t in (v_src, v_tgt):
             t.record_stream(_helper.stream(dev))
@@ -223,43 +219,37 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
                         tseg.append(p)
                         perms.append(cfg + [-3] * (8 - len(cfg)))
                         cfg_pair.append(p)
-                perm_t = torch.tensor(perms, dtype=torch.int32, device=dev)
-                # stable partition of every query cloud by part label (split_corr concatenates the parts
-                # in order, rows in original order inside a part): one stable sort of (pair, label) keys.
-                # The labelled search runs on the partitioned rows, so a wave of 64 queries shares one
-                # label and skips the targets of the other parts wholesale.
-                seg_rows = torch.repeat_interleave(torch.arange(P, device=dev, dtype=torch.int64),
-                                                   torch.tensor(n0, device=dev, dtype=torch.int64),
-                                                   output_size=off0[-1])
-                sorted_rows = torch.sort(seg_rows * 8 + lab0.to(torch.int64).clamp(0, 7), stable=True).indices
-                nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
-                                    qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
-                # Assemble the correspondences of every configuration with a handful of device ops (no
-                # per-configuration launch or host round trip): configuration j owns the query rows
-                # sorted_rows[off0[p] : off0[p+1]] and the result rows nn_cfg[row_j : row_j + n0[p]].
+                # one small upload for everything the device needs from the host here: segment offsets,
+                # configuration row ranges, part permutations
                 lens = np.asarray([n0[p] for p in cfg_pair], dtype=np.int64)
                 row_start = np.concatenate([[0], np.cumsum(lens)])
-                # a CAD part with fewer than k voxels leaves -1 entries: the reference cannot build that
-                # configuration (one reduction + one small copy decides all of them)
-                neg = torch.cumsum((nn_cfg < 0).any(dim=1).to(torch.int32), 0)
-                neg = torch.cat([neg.new_zeros(1), neg])
-                ends = torch.from_numpy(row_start).to(dev)
-                bad = to_host(neg[ends[1:]] - neg[ends[:-1]])[0] > 0
-                keep = [j for j in range(len(cfg_pair)) if not bad[j]]
+                n_cfg = len(cfg_pair)
+                host_blk = np.concatenate([np.asarray(off0, np.int64), row_start,
+                                           np.asarray(perms, np.int32).reshape(-1).view(np.int64)])
+                dev_blk = torch.from_numpy(host_blk).to(dev)
+                off0_t = dev_blk[:P + 1]
+                first_t = dev_blk[P + 1:P + 2 + n_cfg]
+                perm_t = dev_blk[P + 2 + n_cfg:].view(torch.int32).view(n_cfg, 8)
+                # stable partition of every query cloud by part label (split_corr concatenates the parts
+                # in order, rows in original order inside a part): one launch.  The labelled search runs on
+                # the partitioned rows, so a wave of 64 queries shares one label and skips the targets of
+                # the other parts wholesale.
+                sorted_rows = B.partition_by_label(lab0, off0_t, P)
+                nn_cfg = B.knn_feat(baseF[sorted_rows], off0, posF, off1, k, qseg=qseg, tseg=tseg,
+                                    qlabel=lab0[sorted_rows].contiguous(), tlabel=lab1, perm=perm_t)
+                # configuration j owns the query rows sorted_rows[off0[p] : off0[p+1]] and the result rows
+                # nn_cfg[row_start[j] : row_start[j+1]].  A CAD part with fewer than k voxels leaves -1 entries:
+                # the reference cannot build that configuration (one launch + one small copy decide all of them)
+                bad = to_host(B.cfg_bad(nn_cfg, first_t, n_cfg))[0] > 0
+                keep = [j for j in range(n_cfg) if not bad[j]]
                 if keep:
-                    L = torch.from_numpy(lens[keep]).to(dev)
-                    total = int(lens[keep].sum())
-                    seg_first = torch.cumsum(L, 0) - L
-                    base = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(
-                        seg_first, L, output_size=total)
-                    q_first = torch.tensor([off0[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
-                    n_first = torch.from_numpy(row_start[:-1][keep]).to(dev)
-                    t_first = torch.tensor([off1[cfg_pair[j]] for j in keep], device=dev, dtype=torch.int64)
-                    q_rows = torch.repeat_interleave(q_first, L, output_size=total) + base
-                    n_rows = torch.repeat_interleave(n_first, L, output_size=total) + base
-                    prob_src.append(sorted_rows[q_rows].repeat_interleave(k))
-                    prob_tgt.append((nn_cfg[n_rows].to(torch.int64)
-                                     + torch.repeat_interleave(t_first, L, output_size=total)[:, None]).reshape(-1))
+                    out_first = np.concatenate([[0], np.cumsum(lens[keep])])
+                    desc = np.asarray([[off0[cfg_pair[j]], row_start[j], off1[cfg_pair[j]], lens[j], out_first[i]]
+                                       for i, j in enumerate(keep)], dtype=np.int64)
+                    s_src, s_tgt = B.corr_assemble(xyz0, xyz1, sorted_rows, nn_cfg, desc, int(out_first[-1]),
+                                                   int(lens[keep].max()))
+                    corr_src.append(s_src)
+                    corr_tgt.append(s_tgt)
                     for j in keep:
                         prob_len.append(n0[cfg_pair[j]] * k)
                         prob_pair.append(cfg_pair[j])
@@ -274,18 +264,15 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
 
     # ---- 4. RANSAC over all hypotheses (registration_based_on_corr, utils/eval_pose.py:82-100) ----
     if vanilla is None:
-        src_idx = torch.cat(prob_src)
-        tgt_idx = torch.cat(prob_tgt)
+        src = corr_src[0] if len(corr_src) == 1 else torch.cat(corr_src)
+        tgt = corr_tgt[0] if len(corr_tgt) == 1 else torch.cat(corr_tgt)
         offs = np.concatenate([[0], np.cumsum(prob_len)]).tolist()
-        T, inl, rmse, iters = B.ransac_batch(xyz0[src_idx], xyz1[tgt_idx], offs, max_corr, 10, max_iter,
-                                             confidence, seed)
+        T, inl, rmse, iters = B.ransac_batch(src, tgt, offs, max_corr, 10, max_iter, confidence, seed)
     else:
         parts = []
-        if len(prob_src) > 1:
-            src_idx = torch.cat(prob_src[1:])
-            tgt_idx = torch.cat(prob_tgt[1:])
+        if len(corr_src) > 1:
             offs = np.concatenate([[0], np.cumsum(prob_len[P:])]).tolist()
-            parts = [B.ransac_batch(xyz0[src_idx], xyz1[tgt_idx], offs, max_corr, 10, max_iter, confidence, seed)]
+            parts = [B.ransac_batch(corr_src[1], corr_tgt[1], offs, max_corr, 10, max_iter, confidence, seed)]
         first = vanilla.result()              # cs_ransac_batch returns with its stream drained
         cur = torch.cuda.current_stream(dev)
         for t in first:

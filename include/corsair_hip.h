@@ -254,6 +254,25 @@ int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, cons
                      const double* d_sel_centers, int32_t* d_labels, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Correspondence assembly of sym_pose.  Replaces the index plumbing between find_kcorr / split_corr and
+ * registration_based_on_corr (utils/eval_pose.py:48-87, utils/symmetry.py:145-179, 303-356): the reference
+ * builds, per part configuration, `xyzA_corrs` / `xyzB_corrs` by boolean-mask gathers and np.concatenate.
+ *   cs_partition_by_label: d_label int32 [N] (part label per voxel, clamped to 0..7), d_off int64 [n_cloud+1]
+ *     (DEVICE) -> d_order int64 [N]: rows of every cloud stably partitioned by label (parts in order, original
+ *     order inside a part).
+ *   cs_cfg_bad: d_nn int32 [.., k], d_first int64 [n_cfg+1] (DEVICE, row ranges) -> d_bad int32 [n_cfg]: 1 when a
+ *     range holds a negative neighbour (a CAD part with fewer than k voxels; the reference dies there, this
+ *     build drops the configuration, DESIGN "Deliberate differences").
+ *   cs_corr_assemble: d_desc int64 [n_cfg,5] (DEVICE) = {q_first, n_first, t_first, len, out_first} per
+ *     configuration; writes d_src / d_tgt f32 [sum len * k, 3]: query point of d_rows[q_first + i] (d_rows NULL:
+ *     row q_first + i) repeated k times against CAD points t_first + d_nn[n_first + i][0..k).  max_len = largest len.
+ * ---------------------------------------------------------------------------------------- */
+int cs_partition_by_label(const int32_t* d_label, const int64_t* d_off, int n_cloud, int64_t* d_order, void* stream);
+int cs_cfg_bad(const int32_t* d_nn, int k, const int64_t* d_first, int n_cfg, int32_t* d_bad, void* stream);
+int cs_corr_assemble(const float* d_xyz0, const float* d_xyz1, const int64_t* d_rows, const int32_t* d_nn, int k,
+                     const int64_t* d_desc, int n_cfg, int64_t max_len, float* d_src, float* d_tgt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Profiling hooks for bench.py: when enabled the library brackets the launches of each named
  * kernel family with hipEvents on the launch stream and accumulates the elapsed time.
  * names: "conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut",

@@ -34,6 +34,43 @@ def num_threads():
     return int(load().oc_get_threads())
 
 
+def cores_visible():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cgroup_cpu_quota():
+    """CPUs the cgroup may use (cpu.max / cfs quota), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = int(f.read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def cpu_share():
+    n = cores_visible()
+    q = cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, q)
+    cap = int(os.environ.get("ORACLE_THREADS", "16") or 16)
+    return max(1, min(n, cap))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -70,12 +107,12 @@ def load():
         lib.oc_voxel_index.argtypes = [vp, c_int64, c_float, vp]
         lib.oc_set_threads.argtypes = [c_int]
         lib.oc_get_threads.restype = c_int
-        # never oversubscribe: the GPU box exposes many more logical CPUs than its share
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        lib.oc_set_threads(max(1, min(16, avail)))
+        # OpenMP threads = the CPU SHARE of the process, not the logical CPUs it can see: a one-GPU box of the
+        # pool shows every CPU of its host in the affinity mask but is entitled to 16 of them, and spinning
+        # OpenMP threads beyond the share stall each other (a round-3 run with one thread per visible CPU sat
+        # > 7 minutes in one oracle call).  Share = min(affinity, cgroup quota if any, ORACLE_THREADS or 16);
+        # bench.py prints threads used next to cores_visible.
+        lib.oc_set_threads(cpu_share())
         _lib = lib
     return _lib
 
