@@ -56,7 +56,7 @@ FULL_SHAPE_CPU = {
 SYM_HISTOGRAM = {"chair": {1: 650, 4: 2}, "table": {1: 233, 2: 422, 3: 7, 4: 128, 12: 40}}
 QUERY_POOL = {"chair": 993, "table": 291}
 FAMILIES = ("conv", "ransac_eval", "ransac_pre", "ransac_hyp", "knn", "chamfer", "topk", "symcut", "kmap")
-KERNEL_OF = {"conv": "k_conv_mfma", "ransac_eval": "k_ransac_count", "ransac_pre": "k_ransac_prefilter",
+KERNEL_OF = {"conv": "k_conv_dma", "ransac_eval": "k_ransac_count", "ransac_pre": "k_ransac_prefilter",
              "knn": "k_knn_f16", "chamfer": "k_chamfer_mfma", "topk": "k_topk_f16"}
 PEAK_OF = {"knn": F16_PEAK_TFLOPS, "chamfer": F64_PEAK_TFLOPS, "ransac_pre": F16_PEAK_TFLOPS,
            "topk": F16_PEAK_TFLOPS}
@@ -489,11 +489,19 @@ class StressWorkload:
             self.batches.append((torch.from_numpy(np.concatenate(chunk)).to(ctx.dev),
                                  np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist()))
         self.cloud_sample = clouds[:2]
-        # descriptors: Philox standard normal, row-normalised; generated in slabs
-        self.x = torch.empty((self.C, self.d), dtype=torch.float32, device=ctx.dev)
+        # descriptors: Philox standard normal, row-normalised; generated in slabs.  N > 1: every rank
+        # holds ONE contiguous shard of the catalog (C / N rows); the queries travel (sharding.sharded_topk)
+        from corsair_amd import sharding
+
+        self.shard = sharding.catalog_shard(self.C, ctx.rank, ctx.world)
+        first, last = self.shard
+        self.x = torch.empty((last - first, self.d), dtype=torch.float32, device=ctx.dev)
         for i, s in enumerate(range(0, self.C, 131072)):
             n = min(131072, self.C - s)
-            self.x[s:s + n] = torch.from_numpy(synth.make_descriptors(n, self.d, seed=4321 + i)).to(ctx.dev)
+            a, b = max(s, first), min(s + n, last)
+            if a < b:
+                slab = synth.make_descriptors(n, self.d, seed=4321 + i)
+                self.x[a - first:b - first] = torch.from_numpy(slab[a - s:b - s]).to(ctx.dev)
         nq = 65536
         self.q = torch.from_numpy(synth.make_descriptors(nq, self.d, seed=1234 + ctx.rank)).to(ctx.dev)
         torch.cuda.synchronize()
@@ -510,7 +518,16 @@ class StressWorkload:
             self.voxels += last.F.shape[0]
             self.clouds += len(off) - 1
         s = (b * self.TOPK_PER_STEP) % (self.q.shape[0] - self.TOPK_PER_STEP + 1)
-        idx = B.l2_topk(self.q[s:s + self.TOPK_PER_STEP], self.x, 10)
+        qs = self.q[s:s + self.TOPK_PER_STEP]
+        if self.ctx.world == 1:
+            idx = B.l2_topk(qs, self.x, 10)
+        else:
+            # catalog sharded over the ranks: all-gather the queries, top-10 per shard, all-gather the candidate
+            # lists, merge (the one real exchange of this workload, inside the timed step)
+            from corsair_amd import sharding
+
+            idx, _ = sharding.sharded_topk(self.ctx.dist, qs, lambda qq: B.l2_topk(qq, self.x, 10, True, squared=True),
+                                           self.shard[0], 10, self.ctx.rank, self.ctx.world)
         self.results.append((b, idx[:64].cpu().numpy(), last.desc[:4].cpu().numpy()))
 
     def same_results(self, a, b):
@@ -598,17 +615,75 @@ def roofline_of(fam, solo, args):
         r["achieved_executed"] = achieved * 3.0   # x_hi q_hi + x_lo q_hi + x_hi q_lo
         r["frac_executed"] = r["achieved_executed"] / peak
     # HBM bytes per launch and SQ pipe-busy fractions of the dominant kernel from separate rocprofv3 --pmc
-    # runs of this same command (summaries committed under profiles/)
-    tpath = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("kernel") == r["kernel"]:
-            r["traffic"] = tj.get("hbm_bytes_per_launch")
-            for k in ("mfma_busy", "valu_active", "wait_any", "source"):
-                if k in tj:
-                    r[k if k != "source" else "counters_source"] = tj[k]
+    # runs of this same command (profiles/pmc_<workload>.json, tools/pmc_collect.sh).  They describe the kernels
+    # they were collected on: attached only while corsair_amd/csrc is byte-identical to that collection
+    pmc = load_pmc(args.workload)
+    if pmc is None:
+        r["counters"] = "none collected for this workload"
+    elif pmc.get("csrc_sha") != csrc_sha():
+        r["counters"] = "stale: profiles/pmc_%s.json was collected on other kernel sources (%s, now %s)" % (
+            args.workload, pmc.get("csrc_sha"), csrc_sha())
+    elif pmc.get("kernel") == r["kernel"]:
+        r["traffic"] = pmc.get("hbm_bytes_per_launch")
+        for k in ("mfma_busy", "valu_active", "wait_any", "source"):
+            if k in pmc:
+                r[k if k != "source" else "counters_source"] = pmc[k]
     return r
+
+
+_CSRC_SHA = None
+
+
+def csrc_sha():
+    """Hash of the kernel sources (same function as tools/pmc_to_json.py)."""
+    global _CSRC_SHA
+    if _CSRC_SHA is None:
+        import hashlib
+
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "corsair_amd", "csrc")
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+        _CSRC_SHA = h.hexdigest()[:16]
+    return _CSRC_SHA
+
+
+def load_pmc(workload):
+    tpath = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        return json.load(f)
+
+
+def roofline_by_kernel(fam, args):
+    """Per kernel family of the timed region: achieved TFLOP/s in SURVEY 8d units (this run's event time) and --
+    where the committed PMC pass matches the kernel sources -- HBM GB/s = PMC bytes per library call x this run's
+    calls / this run's event time, with the fraction of the 8 TB/s HBM peak, and the matrix-pipe busy share."""
+    pmc = load_pmc(args.workload)
+    fresh = pmc is not None and pmc.get("csrc_sha") == csrc_sha()
+    out = {}
+    for name in FAMILIES:
+        d = fam.get(name)
+        if not d or d["launches"] == 0 or d["ms"] <= 0:
+            continue
+        e = {"ms": round(d["ms"], 3), "calls": d["launches"]}
+        if d["flop"] > 0:
+            tf = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            peak = PEAK_OF.get(name, F32_PEAK_TFLOPS)
+            e.update({"tflops": round(tf, 2), "peak_tflops": peak, "frac_of_matrix_peak": round(tf / peak, 4)})
+        pf = pmc.get("families", {}).get(name) if fresh else None
+        if pf:
+            gbs = pf["hbm_bytes_per_call"] * d["launches"] / (d["ms"] * 1e-3) / 1e9
+            e.update({"hbm_gb_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / 8000.0, 4),
+                      "hbm_mb_per_call": round(pf["hbm_bytes_per_call"] / 1e6, 2),
+                      "mfma_busy": round(pf["mfma_busy"], 3), "valu_active": round(pf["valu_active"], 3)})
+        out[name] = e
+    if not fresh:
+        out["counters"] = "none" if pmc is None else "stale (profiles/pmc_%s.json predates the kernel sources)" % args.workload
+    return out
 
 
 def main():
@@ -745,6 +820,7 @@ def main():
             "data": "synthetic",
             "config": cfg,
             "roofline": roofline_of(fam, solo, args),
+            "roofline_by_kernel": roofline_by_kernel(fam, args),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         }
         if args.workload == "stress":

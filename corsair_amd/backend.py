@@ -249,13 +249,14 @@ def voxelize(xyz, offsets, voxel_size):
     return keep[:m], grid[:m], out_off
 
 
-def l2_topk(q, x, k, return_distance=False):
+def l2_topk(q, x, k, return_distance=False, squared=False):
+    """squared=True (with return_distance): the squared distances the ranking was made on (shard merges)."""
     q = _dev(q, torch.float32, "queries").contiguous()
     x = _dev(x, torch.float32, "catalog").contiguous()
     idx = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
     dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=q.device) if return_distance else None
-    check(_lib.load().cs_l2_topk(ptr(q), q.shape[0], ptr(x), x.shape[0], q.shape[1], k, ptr(idx),
-                                 ptr(dist), stream_ptr()))
+    fn = _lib.load().cs_l2_topk_sq if squared else _lib.load().cs_l2_topk
+    check(fn(ptr(q), q.shape[0], ptr(x), x.shape[0], q.shape[1], k, ptr(idx), ptr(dist), stream_ptr()))
     return (idx, dist) if return_distance else idx
 
 

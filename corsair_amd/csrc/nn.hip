@@ -975,13 +975,17 @@ __global__ void k_topk_init(unsigned long long* carry_d, int* carry_i, int64_t n
     carry_i[t] = 0x7fffffff;
   }
 }
+// squared: write the squared distances the ranking was made on (cs_l2_topk_sq: shard merges compare exactly
+// what the kernels compared; two different squares can share one rounded square root)
+static thread_local int t_topk_squared = 0;
 __global__ void k_topk_finish(const unsigned long long* carry_d, const int* carry_i, int64_t n,
-                              int64_t* idx, double* dist) {
+                              int64_t* idx, double* dist, int squared) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t < n) {
     int i = carry_i[t];
     idx[t] = i == 0x7fffffff ? -1 : (int64_t)i;
-    if (dist) dist[t] = sqrt(__longlong_as_double((long long)carry_d[t]));
+    const double d2 = __longlong_as_double((long long)carry_d[t]);
+    if (dist) dist[t] = squared ? d2 : sqrt(d2);
   }
 }
 
@@ -1825,7 +1829,7 @@ static int topk_f64_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand,
                      k, cd.p, ci.p);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
-                     ci.p, nq * k, d_idx, d_dist);
+                     ci.p, nq * k, d_idx, d_dist, t_topk_squared);
   CS_LAUNCH_CHECK();
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
@@ -1883,7 +1887,7 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_tkf_verify, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, cd.p, k, nq, tau.p,
                      nlane, qn.p, xmax.p, d, terms, flagged.p, n_flagged);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p, ci.p,
-                     nq * k, d_idx, d_dist);
+                     nq * k, d_idx, d_dist, t_topk_squared);
   CS_LAUNCH_CHECK();
   int h_flagged = 0;
   CS_HIP_CHECK(download_async(&h_flagged, n_flagged, sizeof(int), s));
@@ -1912,6 +1916,14 @@ void cs_l2_topk_stats(uint64_t out[2], int reset) {
     if (out) out[i] = g_topk_stats[i].load();
     if (reset) g_topk_stats[i].store(0);
   }
+}
+
+int cs_l2_topk_sq(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k, int64_t* d_idx,
+                  double* d_dist2, void* stream) {
+  t_topk_squared = 1;
+  const int rc = cs_l2_topk(d_q, nq, d_x, nx, d, k, d_idx, d_dist2, stream);
+  t_topk_squared = 0;
+  return rc;
 }
 
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
@@ -1952,7 +1964,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
                        ci.p);
   }
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
-                     ci.p, nq * k, d_idx, d_dist);
+                     ci.p, nq * k, d_idx, d_dist, t_topk_squared);
   CS_LAUNCH_CHECK();
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }

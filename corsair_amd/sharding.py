@@ -121,3 +121,58 @@ def gather_catalog(dist, local_set, n_items, world, shards=None):
     sets = all_gather_embedded(dist, local_set, world)
     order = global_order(n_items, world) if shards is None else shard_order(shards)
     return concat_sets(sets).gather(order)
+
+
+# ---- catalog-sharded descriptor top-k (the 10^6 x 10^6 case, 1 GB of descriptors) ---------------
+def merge_topk(d2_lists, gid_lists, k):
+    """k best of the concatenated per-shard candidate lists, ranked by (squared distance, global id) -- the
+    order cs_l2_topk itself uses (ties -> smaller catalog index).  d2_lists / gid_lists: per shard a [Q, k_s]
+    float64 / int64 tensor (absent entries: id -1 with distance inf).  Two stable sorts give the lexicographic
+    order: by id first, then by distance."""
+    d2 = torch.cat(list(d2_lists), dim=1)
+    gid = torch.cat(list(gid_lists), dim=1)
+    big = torch.iinfo(torch.int64).max
+    key = torch.where(gid < 0, torch.full_like(gid, big), gid)
+    o1 = torch.sort(key, dim=1, stable=True).indices
+    d2, gid = torch.gather(d2, 1, o1), torch.gather(gid, 1, o1)
+    o2 = torch.sort(d2, dim=1, stable=True).indices[:, :k]
+    return torch.gather(gid, 1, o2), torch.gather(d2, 1, o2)
+
+
+def _all_gather_rows(dist, t, world):
+    """all_gather of equally shaped tensors (one flat collective where the backend has it)."""
+    stage = _stage_device(dist, t)
+    src = t.to(stage).contiguous()
+    out = torch.empty((world,) + tuple(src.shape), device=stage, dtype=src.dtype)
+    if hasattr(dist, "all_gather_into_tensor") and dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, src)
+    else:
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, src)
+    return out.to(t.device)
+
+
+def sharded_topk(dist, q_local, local_topk, shard_first, k, rank, world):
+    """Top-k of this rank's queries against a catalog sharded over the ranks (rank r holds the contiguous rows
+    [shard_first, shard_first + n_r)).  The QUERIES travel, not the catalog: (1) all-gather the
+    queries (every rank contributes the same number), (2) `local_topk(q_all) -> (local row idx int64 [., k],
+    squared distance f64 [., k])` against the own shard (cs_l2_topk_sq), (3) all-gather the candidate
+    (distance, global id) lists, (4) merge the `world` lists of the own queries.  Returns (ids int64 [Q, k],
+    d2 f64 [Q, k]): identical to a single-device top-k over the whole catalog, bit for bit."""
+    if dist is None or world == 1:
+        idx, d2 = local_topk(q_local)
+        return idx + (idx >= 0) * shard_first, d2
+    Q = q_local.shape[0]
+    q_all = _all_gather_rows(dist, q_local, world).reshape(world * Q, -1)
+    idx, d2 = local_topk(q_all)
+    gid = torch.where(idx >= 0, idx + shard_first, idx)
+    gids = _all_gather_rows(dist, gid, world)                 # [world (shard), world * Q, k]
+    d2s = _all_gather_rows(dist, d2, world)
+    mine = slice(rank * Q, (rank + 1) * Q)
+    return merge_topk([d2s[r, mine] for r in range(world)], [gids[r, mine] for r in range(world)], k)
+
+
+def catalog_shard(n_items, rank, world):
+    """Contiguous row range [first, last) of the descriptor catalog owned by `rank`."""
+    per = (n_items + world - 1) // world
+    return min(rank * per, n_items), min((rank + 1) * per, n_items)

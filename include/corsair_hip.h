@@ -153,6 +153,11 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
  * ---------------------------------------------------------------------------------------- */
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
                int64_t* d_idx, double* d_dist, void* stream);
+/* Same, but d_dist2 receives the SQUARED distances the ranking was made on: what a multi-GPU run merges the
+ * per-shard lists with (catalog sharded over ranks, corsair_amd/sharding.py sharded_topk; the reference is
+ * single-device).  Merging by (squared distance, global index) reproduces the single-device list bit for bit. */
+int cs_l2_topk_sq(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k, int64_t* d_idx,
+                  double* d_dist2, void* stream);
 /* Diagnostics of the large-size path (nq * nx >= 2^24, d = 64 / 128 / 256, k <= 10: shortlist on the
  * f16 matrix cores, exact re-score, verification): {queries that took it, queries recomputed by the
  * f64 path because the verification failed (ties at the k-th neighbour)}. */

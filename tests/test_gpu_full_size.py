@@ -192,3 +192,58 @@ def test_knn_and_chamfer_full_size_properties(gpu):
                         [0, 1], [0, 1], torch.from_numpy(np.stack([Tm, shift])).to(gpu)).cpu().numpy()
     assert cd[0] < 1e-6                                # f32 transform of the same points
     assert 0.0 < cd[1] <= 0.25 + 1e-6
+
+
+def test_topk_contract_size_1M_x_1M(gpu, monkeypatch):
+    """BASELINE.json configs[4] at CONTRACT size: top-10 of 10^6 queries against a 10^6 x 256-d catalog of
+    row-normalised descriptors.  Size-independent properties on every query (sorted distances, ids in range,
+    unique) and a 64-query spot check against the exact slab path (f64 distance of every pair).  The descriptors
+    are drawn on the device (10^6 x 256 Philox normals on the host take longer than the search)."""
+    from corsair_amd import backend as B
+
+    n, d, k, slab = 1000000, 256, 10, 65536
+    g = torch.Generator(device=gpu).manual_seed(4321)
+    x = torch.randn((n, d), generator=g, device=gpu)
+    x /= torch.linalg.norm(x, dim=1, keepdim=True)
+    q = torch.randn((n, d), generator=g, device=gpu)
+    q /= torch.linalg.norm(q, dim=1, keepdim=True)
+    idx = torch.empty((n, k), dtype=torch.int64, device=gpu)
+    sorted_ok = torch.ones((), dtype=torch.bool, device=gpu)
+    for s in range(0, n, slab):
+        i, dist = B.l2_topk(q[s:s + slab], x, k, True)
+        idx[s:s + slab] = i
+        sorted_ok &= (dist[:, 1:] >= dist[:, :-1]).all()
+    assert bool(sorted_ok)
+    assert bool((idx >= 0).all()) and bool((idx < n).all())
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    sample = torch.arange(0, n, n // 64, device=gpu)[:64]
+    monkeypatch.setenv("CS_TOPK_MFMA", "0")
+    ref = B.l2_topk(q[sample].contiguous(), x, k)
+    assert torch.equal(idx[sample], ref)
+
+
+def test_sharded_topk_merge_equals_single_device(gpu):
+    """The catalog split into 3 contiguous shards, cs_l2_topk_sq per shard, sharding.merge_topk over the
+    (squared distance, global id) lists == cs_l2_topk over the whole catalog, bit for bit (ids and distances):
+    what every rank of a multi-GPU run computes (tests/test_sharding_gloo.py covers the exchange)."""
+    from corsair_amd import backend as B, sharding, synth
+
+    nq, nx, k = 4096, 200000, 10
+    q = torch.from_numpy(synth.make_descriptors(nq, 256, seed=77)).to(gpu)
+    x = torch.from_numpy(synth.make_descriptors(nx, 256, seed=78)).to(gpu)
+    x[150000] = x[20]                       # exact ties across shard boundaries
+    q[5] = x[20]
+    want_idx, want_d2 = B.l2_topk(q, x, k, True, squared=True)
+    d2s, gids = [], []
+    for r in range(3):
+        first, last = sharding.catalog_shard(nx, r, 3)
+        i, d2 = B.l2_topk(q, x[first:last].contiguous(), k, True, squared=True)
+        d2s.append(d2)
+        gids.append(i + first)
+    ids, d2 = sharding.merge_topk(d2s, gids, k)
+    assert torch.equal(ids, want_idx) and torch.equal(d2, want_d2)
+    assert int(ids[5, 0]) == 20 and int(ids[5, 1]) == 150000
+    # the plain entry point returns the square roots of the same values
+    _, dist = B.l2_topk(q, x, k, True)
+    assert torch.equal(dist, torch.sqrt(want_d2))

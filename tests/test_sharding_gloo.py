@@ -125,3 +125,62 @@ def test_balanced_catalog_all_gather_world2(tmp_path):
     mp.spawn(_count_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def _exact_topk(q, x, k):
+    """Reference local top-k: exact f64 squared distances (the oracle's fma chain), ties -> smaller index."""
+    from oracle import native
+
+    d2 = native.dist2_matrix(q.numpy(), x.numpy())
+    idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    return torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(np.take_along_axis(d2, idx, 1))
+
+
+def _topk_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from corsair_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        C, d, k, Q = 301, 24, 10, 17
+        x = torch.randn(C, d, generator=g)
+        x[37] = x[200]                      # exact ties across the shard boundary: the smaller global index wins
+        x[151] = x[150]
+        q_all = torch.randn(world * Q, d, generator=g)
+        q_all[3] = x[200]
+        first, last = sharding.catalog_shard(C, rank, world)
+        q_mine = q_all[rank * Q:(rank + 1) * Q]
+        ids, d2 = sharding.sharded_topk(dist, q_mine, lambda qq: _exact_topk(qq, x[first:last], k), first, k, rank, world)
+        want_ids, want_d2 = _exact_topk(q_mine, x, k)
+        ok = torch.equal(ids, want_ids) and torch.equal(d2, want_d2)
+        with open(os.path.join(out_dir, f"topk{rank}.txt"), "w") as f:
+            f.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_topk_world2_equals_single_rank(tmp_path, oracle_native):
+    """Catalog sharded over 2 ranks, queries all-gathered, per-shard lists merged by (squared distance, global
+    id): ids and distances equal the unsharded top-k bit for bit, ties across the shard boundary included."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_topk_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"topk{r}.txt").read_text() == "ok"
+
+
+def test_merge_topk_orders_by_distance_then_id():
+    from corsair_amd import sharding
+
+    d2a = torch.tensor([[1.0, 2.0, 2.0]], dtype=torch.float64)
+    ida = torch.tensor([[7, 9, 11]])
+    d2b = torch.tensor([[2.0, 2.0, float("inf")]], dtype=torch.float64)
+    idb = torch.tensor([[3, 10, -1]])
+    ids, d2 = sharding.merge_topk([d2a, d2b], [ida, idb], 4)
+    assert ids.tolist() == [[7, 3, 9, 10]] and d2.tolist() == [[1.0, 2.0, 2.0, 2.0]]
+    assert sharding.catalog_shard(10, 3, 4) == (9, 10) and sharding.catalog_shard(10, 0, 4) == (0, 3)

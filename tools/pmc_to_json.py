@@ -1,17 +1,43 @@
 """Distil the three rocprofv3 --pmc passes of tools/pmc_collect.sh into <outdir>/pmc.json (copied to
-profiles/pmc_<workload>.json, which bench.py reads into `roofline.traffic` / `mfma_busy` / ...) and a text table of
-every library kernel.  Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
-FETCH_SIZE tallies 16-B/lane streaming reads at half their bytes, so kernels that stream through LDS-DMA or
-dwordx4 loads (listed in WIDE) get FETCH doubled; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles,
-SQ_VALU_MFMA_BUSY_CYCLES cycles; utilisation = busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
-import collections, csv, glob, json, sys
+profiles/pmc_<workload>.json, which bench.py reads into `roofline.traffic` / `mfma_busy` and `roofline_by_kernel`)
+and a text table of every library kernel.  Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are
+KiB; on gfx950 FETCH_SIZE tallies 16-B/lane streaming reads at half their bytes, so kernels that stream through
+LDS-DMA or dwordx4 loads (listed in WIDE) get FETCH doubled; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are
+quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; utilisation = busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
+
+The file carries `csrc_sha` (hash of corsair_amd/csrc sources at collection time): bench.py attaches the counters
+only while the kernels are unchanged, otherwise it prints traffic: null and counters: "stale" (ADVICE r2)."""
+import collections, csv, glob, hashlib, json, os, sys
 
 out = sys.argv[1]
 workload = "chair"
 if "--workload" in sys.argv:
     workload = sys.argv[sys.argv.index("--workload") + 1]
-WIDE = ("k_ransac_prefilter", "k_knn_f16", "k_topk_f16", "k_conv_mfma", "k_conv_lacc")
-DOMINANT = {"chair": "k_ransac_prefilter", "table": "k_ransac_prefilter", "stress": "k_conv_mfma"}[workload]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDE = ("k_ransac_prefilter", "k_knn_f16", "k_topk_f16", "k_conv_mfma", "k_conv_dma")
+DOMINANT = {"chair": "k_ransac_prefilter", "table": "k_ransac_prefilter", "stress": "k_conv_dma"}[workload]
+# kernel family of bench.py's `kernel_ms` -> (kernels that belong to it, kernels of which ONE launch = one library call)
+FAMILY = {
+    "conv": (("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic"), ("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic")),
+    "kmap": (("k_build_nbr", "k_row_keys", "k_sorted_tables", "k_insert", "k_emit_strided", "k_flag_first", "k_segments", "k_fill_table"), ("k_row_keys",)),
+    "knn": (("k_knn_f16", "k_knn_rescore_f16", "k_knf_pack", "k_knn_feat"), ("k_knf_pack_queries",)),
+    "chamfer": (("k_chamfer",), ("k_chamfer_mfma", "k_chamfer<")),
+    "topk": (("k_topk", "k_tkf", "k_dist_matrix", "k_row_topk"), ("k_topk_finish",)),
+    "ransac_pre": (("k_ransac_prefilter",), ("k_ransac_prefilter",)),
+    "ransac_hyp": (("k_ransac_hyp<", "k_ransac_hypILi"), ("k_ransac_hyp<", "k_ransac_hypILi")),
+    "ransac_eval": (("k_ransac_count", "k_ransac_err", "k_ransac_scan", "k_ransac_survivors"), ("k_ransac_scan1",)),
+    "symcut": (("k_symcut",), ("k_symcut_kmeans",)),
+}
+
+
+def csrc_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "corsair_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load(tag):
@@ -62,13 +88,33 @@ with open(f"{out}/pmc_table.txt", "w") as f:
     for r in rows:
         f.write(f"{r['kernel']:46s} {r['launches']:8d} {r['hbm_bytes_per_launch'] / 1e6:14.2f} {r['mfma_busy']:9.3f} "
                 f"{r['valu_active']:6.3f} {r['wait_any']:8.3f} {r['wait_inst']:9.3f} {r['kcycles_per_launch']:8.0f}\n")
+
+
+def weighted(sel, keys):
+    n = sum(r["launches"] for r in sel)
+    cyc = sum(r["kcycles_per_launch"] * r["launches"] for r in sel) or 1.0
+    agg = {"hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / max(n, 1)}
+    for k in keys:   # busy fractions: weighted by the time the kernels ran
+        agg[k] = sum(r[k] * r["kcycles_per_launch"] * r["launches"] for r in sel) / cyc
+    return n, agg
+
+
 dom = [r for r in rows if DOMINANT in r["full"]]
+families = {}
+for fam, (members, anchors) in FAMILY.items():
+    sel = [r for r in rows if any(m in r["full"] for m in members)]
+    calls = sum(r["launches"] for r in rows if any(a in r["full"] for a in anchors))
+    if not sel or not calls:
+        continue
+    total_bytes = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel)
+    _, agg = weighted(sel, ("mfma_busy", "valu_active", "wait_any"))
+    families[fam] = {"hbm_bytes_per_call": total_bytes / calls, "calls_profiled": calls,
+                     "mfma_busy": agg["mfma_busy"], "valu_active": agg["valu_active"], "wait_any": agg["wait_any"],
+                     "kernels": sorted({r["kernel"].split("<")[0] for r in sel})}
 if dom:
-    # several template instances of one family: weight by launches
-    n = sum(r["launches"] for r in dom)
-    agg = {k: sum(r[k] * r["launches"] for r in dom) / n for k in
-           ("hbm_bytes_per_launch", "mfma_busy", "valu_active", "wait_any", "wait_inst")}
-    js = {"kernel": DOMINANT, "launches": n, **agg, "fetch_doubled": dom[0]["fetch_doubled"],
+    n, agg = weighted(dom, ("mfma_busy", "valu_active", "wait_any", "wait_inst"))
+    js = {"kernel": DOMINANT, "launches": n, **agg, "fetch_doubled": dom[0]["fetch_doubled"], "families": families,
+          "csrc_sha": csrc_sha(),
           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (three separate passes, tools/pmc_collect.sh) on "
                     "`python bench.py " + " ".join(sys.argv[2:]) + " --steps 3 --warmup 1 --no-cpu-baseline "
                     "--no-overlap-probe --no-solo-probe`"}
