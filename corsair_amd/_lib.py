@@ -63,7 +63,7 @@ def _declare(lib):
         "cs_knn_shortlist_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_l2_topk_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_symcut_fit": (c_int, [vp, c_int, vp, POINTER(c_int64), c_int, vp, c_int,
-                                  POINTER(c_int32), c_int, c_int, c_int, c_uint64, vp, vp, vp, vp, vp]),
+                                  POINTER(c_int32), c_int, c_int, c_int, vp, vp, vp, vp, vp]),
         "cs_symcut_labels": (c_int, [vp, POINTER(c_int64), c_int, POINTER(c_int32), vp, vp, vp]),
         "cs_partition_by_label": (c_int, [vp, vp, c_int, vp, vp]),
         "cs_cfg_bad": (c_int, [vp, c_int, vp, c_int, vp, vp]),

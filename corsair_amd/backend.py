@@ -355,7 +355,7 @@ def corr_assemble(xyz0, xyz1, rows, nn, desc, total, max_len):
     return src, tgt
 
 
-def symcut_fit(feat, xyz, offsets, anchors, Ks, n_nn=50, n_init=10, max_iter=300, seed=0):
+def symcut_fit(feat, xyz, offsets, anchors, Ks, n_nn=50, n_init=10, max_iter=300):
     """anchors int32 [n_cloud, n_anchor] device; Ks host list.  Returns centers f64 [c,a,4,3],
     counts int32 [c,a,4], min centre distance f64 [c,a], max error f64 [c,a]."""
     feat = _dev(feat, torch.float32, "features").contiguous()
@@ -368,7 +368,7 @@ def symcut_fit(feat, xyz, offsets, anchors, Ks, n_nn=50, n_init=10, max_iter=300
     mcd = torch.empty((nc, na), dtype=torch.float64, device=dev)
     mer = torch.empty((nc, na), dtype=torch.float64, device=dev)
     check(_lib.load().cs_symcut_fit(ptr(feat), feat.shape[1], ptr(xyz), i64_array(offsets), nc,
-                                    ptr(anchors), na, i32_array(Ks), n_nn, n_init, max_iter, int(seed),
+                                    ptr(anchors), na, i32_array(Ks), n_nn, n_init, max_iter,
                                     ptr(centers), ptr(counts), ptr(mcd), ptr(mer), stream_ptr()))
     return centers, counts, mcd, mer
 

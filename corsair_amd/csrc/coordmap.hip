@@ -421,6 +421,38 @@ __global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nb
   row[o] = (int32_t)o;
 }
 
+// Row order of a SMALL map (<= SORT_SMALL_MAX rows: the coarse levels of a batch) in one launch: bitonic sort
+// of (key << 32 | row) in LDS by one workgroup.  hipcub's radix sort takes a block-sort + merge path of 5 - 8
+// launches for such sizes (55 launches per chair step over the ten maps of a batch).  Any order of equal keys
+// is fine for the convolution; (key, row) pairs are distinct, so the result is also deterministic.
+constexpr int SORT_SMALL_MAX = 16384;
+__global__ __launch_bounds__(1024) void k_sort_small(const uint32_t* __restrict__ key, int n, int npow2,
+                                                     uint32_t* __restrict__ key_sorted, int32_t* __restrict__ rowlist) {
+  extern __shared__ unsigned long long sk[];
+  for (int i = threadIdx.x; i < npow2; i += 1024)
+    sk[i] = i < n ? ((unsigned long long)key[i] << 32) | (unsigned)i : ~0ULL;
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npow2 >> 1); t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));      // index of the lower element of pair t
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = sk[lo], b = sk[hi];
+        if ((a > b) == up) {
+          sk[lo] = b;
+          sk[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    key_sorted[i] = (uint32_t)(sk[i] >> 32);
+    rowlist[i] = (int32_t)(sk[i] & 0xffffffffu);
+  }
+}
+
 // the neighbour table in tiling order + the offsets every 32-row group of that order uses (one thread per
 // table element; the group masks come from the sorted keys: mask = Gray code of the rank)
 __global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist,
@@ -784,9 +816,11 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
     PoolBuf<uint32_t> key(n), key_sorted(n);
     PoolBuf<int32_t> row(n);
+    const bool small = n <= SORT_SMALL_MAX;
     size_t tmp_bytes = 0;
-    hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist,
-                                                       (int)n, 0, 27, s);
+    hipError_t e2 = small ? hipSuccess
+                          : hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p,
+                                                               km->d_rowlist, (int)n, 0, 27, s);
     PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
     if (!km->d_rowlist || !key.p || !key_sorted.p || !row.p || !tmp.p) {
       cs_kernelmap_free(km);
@@ -796,9 +830,20 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     hipLaunchKernelGGL(k_row_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, km->d_nbr, n, km->kvol, key.p,
                        row.p, d_cnt, cnt_host_dev);
     if (cnt_host_dev && hipEventRecord(km->cnt_ready, s) != hipSuccess) e2 = hipErrorUnknown;
-    if (e2 == hipSuccess)
+    if (small) {
+      int npow2 = 2;
+      while (npow2 < n) npow2 <<= 1;
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_small),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         SORT_SMALL_MAX * (int)sizeof(unsigned long long));
+      e2 = attr;
+      if (e2 == hipSuccess)
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), (size_t)npow2 * sizeof(unsigned long long), s, key.p, (int)n,
+                           npow2, key_sorted.p, km->d_rowlist);
+    } else if (e2 == hipSuccess) {
       e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist, (int)n, 0,
                                               27, s);
+    }
     const int64_t n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
     km->d_nbr_sorted = (int32_t*)pool_alloc((size_t)n * km->kvol * sizeof(int32_t));
     km->d_gmask = (uint32_t*)pool_alloc((size_t)n_groups * sizeof(uint32_t));

@@ -1231,8 +1231,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // first chunk (all hypotheses counted exactly: there is no best count to prune against yet) and first
   // prefiltered iteration.  Round 1 (f32 matrix-pipe exact kernel): 512 = 256, no difference; with the f64
   // exact kernel of round 2 the unfiltered rounds are the expensive ones: 256 instead of 512 is +2.4 % queries/s
-  const int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 256;
-  const int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : first_chunk;
+  // (experiment knobs: clamped -- a first chunk above bmax would index the bmax-sized scratch out of range, 0 would
+  // never advance the chunk loop)
+  int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 256;
+  first_chunk = ((std::min(std::max(first_chunk, 256), bmax) + 255) / 256) * 256;
+  int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : first_chunk;
+  pf_from = std::max(pf_from, first_chunk);
   // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
   // [RansacProb x n_prob | 2 x { n_surv int32 x n_prob (padded to 8 B) | n_active int32 (8 B) }]: the counters
   // exist once per round parity, k_ransac_scan2 clears the set of the next round

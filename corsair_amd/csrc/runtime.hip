@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.h"
+#include <atomic>
 
 namespace cs {
 
@@ -29,12 +30,15 @@ void set_error(const char* fmt, ...) {
 // owner's stream still has in flight on the block finishes first.  Rare and slow by design.
 static std::mutex g_pool_mu;
 struct LiveBlock {
-  size_t cls;           // size class
-  const void* owner;    // identity of the allocating thread (address of its thread-local cache)
+  size_t cls;                  // size class
+  unsigned long long owner;    // id of the allocating thread (monotonic: the ADDRESS of a thread-local cache can
+                               // be handed to a later thread once its owner has exited)
 };
 static std::map<void*, LiveBlock> g_live;             // block -> size class + owner (all threads)
 static unsigned long long g_foreign_frees = 0;        // blocks freed by a thread other than their owner
+static std::atomic<unsigned long long> g_next_thread_id{1};
 struct ThreadCache {
+  const unsigned long long id = g_next_thread_id.fetch_add(1, std::memory_order_relaxed);
   std::map<size_t, std::vector<void*>> free_;          // size class -> blocks
   ~ThreadCache() {
     for (auto& kv : free_)
@@ -93,7 +97,7 @@ void* pool_alloc(size_t bytes) {
     }
   }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_live[p] = LiveBlock{c, &t_cache};
+  g_live[p] = LiveBlock{c, t_cache.id};
   return p;
 }
 
@@ -106,12 +110,13 @@ void pool_free(void* p) {
     if (it == g_live.end()) return;
     b = it->second;
     g_live.erase(it);
-    if (b.owner != &t_cache) ++g_foreign_frees;
+    if (b.owner != t_cache.id) ++g_foreign_frees;
   }
-  if (b.owner != &t_cache) {
+  if (b.owner != t_cache.id) {
     // not ours: the owner's stream may still be reading it and this thread's stream is not ordered
     // against that stream.  hipFree synchronises the device before it releases the memory.
-    (void)hipFree(p);
+    const hipError_t e = hipFree(p);
+    if (e != hipSuccess) set_error("pool_free: hipFree of a block of another thread failed: %s", hipGetErrorString(e));
     return;
   }
   // ours: later work of this thread is enqueued behind whatever still uses the block (same stream, or a

@@ -655,9 +655,10 @@ extern "C" {
 
 int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_t* h_off,
                   int n_cloud, const int32_t* d_anchor, int n_anchor, const int32_t* h_K,
-                  int n_nn, int n_init, int max_iter, uint64_t seed, double* d_centers,
+                  int n_nn, int n_init, int max_iter, double* d_centers,
                   int32_t* d_counts, double* d_min_center_dist, double* d_max_error,
                   void* stream) {
+  const uint64_t seed = 0;   // the draws are sklearn's random_state=0 stream (utils/symmetry.py:216), tabulated
   CS_REQUIRE(d_feat && d_xyz && h_off && d_anchor && h_K && d_centers && d_counts &&
                  d_min_center_dist && d_max_error,
              CS_ERR_INVALID, "cs_symcut_fit: NULL argument");
@@ -666,8 +667,6 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
              "cs_symcut_fit: n_nn %d not in [4, %d]", n_nn, SYM_MAX_NN);
   CS_REQUIRE(n_init >= 1 && n_init <= SYM_MAX_INIT, CS_ERR_UNSUPPORTED,
              "cs_symcut_fit: n_init %d not in [1, %d]", n_init, SYM_MAX_INIT);
-  CS_REQUIRE(seed == 0, CS_ERR_UNSUPPORTED,
-             "cs_symcut_fit: only sklearn's random_state=0 stream is tabulated (utils/symmetry.py:216)");
   CS_REQUIRE(n_anchor >= 1 && max_iter >= 1, CS_ERR_INVALID, "cs_symcut_fit: bad counts");
   if (n_cloud <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;

@@ -200,7 +200,7 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
                 a_all = torch.from_numpy(np.concatenate([anchors_of(anc0), anchors_of(anc1)])).to(dev)
                 off_all = off0 + [off0[-1] + o for o in off1[1:]]
                 c, cnt, mcd, mer = B.symcut_fit(torch.cat([baseF, posF]), torch.cat([xyz0, xyz1]), off_all, a_all,
-                                                Ks + Ks, 50, 10, 300, 0)
+                                                Ks + Ks, 50, 10, 300)
                 c, cnt, mcd, mer = to_host(c, cnt, mcd, mer)
                 c0, cnt0, mcd0, mer0 = c[:P], cnt[:P], mcd[:P], mer[:P]
                 c1, cnt1, mcd1, mer1 = c[P:], cnt[P:], mcd[P:], mer[P:]

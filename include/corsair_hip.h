@@ -239,8 +239,9 @@ void cs_ransac_prefilter_stats(uint64_t out[5], int reset);
  * Symmetry part cut.  Replaces symmetric_cut4 (utils/symmetry.py:182-259) for a batch of
  * clouds: for every (cloud, anchor) the 50 feature-nearest voxels, the fit of
  * sklearn's KMeans(n_clusters=K, random_state=0, n_init=n_init) on their xyz (utils/symmetry.py:216:
- * greedy k-means++ on the constant uniform draws of numpy's RandomState(0), Lloyd with sklearn's
- * stopping rules, first-best restart; `seed` must be 0 = that random_state, n_init <= 10), the
+ * greedy k-means++ on the constant uniform draws of numpy's RandomState(0) -- the reference hard-codes
+ * random_state=0, so the entry point takes no seed --, Lloyd with sklearn's stopping rules, first-best
+ * restart; n_init <= 10: that many restarts' draws are tabulated, more is CS_ERR_UNSUPPORTED), the
  * statistics the acceptance gate needs, and finally the labels of every voxel under the accepted model.
  *   cs_symcut_fit: d_feat f32 [N,dim], d_xyz f32 [N,3], h_off int64 [n_cloud+1],
  *     d_anchor int32 [n_cloud, n_anchor] (row index local to the cloud), h_K int32 [n_cloud] in {2,4};
@@ -252,7 +253,7 @@ void cs_ransac_prefilter_stats(uint64_t out[5], int reset);
  * ---------------------------------------------------------------------------------------- */
 int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_t* h_off,
                   int n_cloud, const int32_t* d_anchor, int n_anchor, const int32_t* h_K,
-                  int n_nn, int n_init, int max_iter, uint64_t seed, double* d_centers,
+                  int n_nn, int n_init, int max_iter, double* d_centers,
                   int32_t* d_counts, double* d_min_center_dist, double* d_max_error,
                   void* stream);
 int cs_symcut_labels(const float* d_xyz, const int64_t* h_off, int n_cloud, const int32_t* h_K,

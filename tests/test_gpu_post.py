@@ -275,7 +275,7 @@ def test_symcut_fit_bit_exact(gpu, oracle_native):
     F, X, off = _engine_features(gpu, [20, 21], [None, None])
     Ks = [2, 4]
     anchors = np.stack([R.draw_anchors(off[c + 1] - off[c], 24, c) for c in range(2)])
-    c, cnt, mcd, mer = B.symcut_fit(F, X, off, torch.from_numpy(anchors).to(gpu), Ks, 50, 10, 300, 0)
+    c, cnt, mcd, mer = B.symcut_fit(F, X, off, torch.from_numpy(anchors).to(gpu), Ks, 50, 10, 300)
     Fh, Xh = F.cpu().numpy(), X.cpu().numpy()
     for i in range(2):
         f, x = Fh[off[i]:off[i + 1]], Xh[off[i]:off[i + 1]]
