@@ -876,13 +876,17 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     if (!cfg) {
       // 128-row tiles (4 row groups share a weight slab) while they still give every CU several workgroups,
       // 64- and 32-row tiles for the coarse levels
-      // the more output columns a wave owns, the more MFMAs each DMA instruction of gathered rows feeds
-      // (NT = 1 / 2 / 4: 16 / 32 / 64 MFMAs per 4 KiB of rows); fewer rows per workgroup where a layer would
-      // otherwise leave CUs without work
+      // measured per layer on the stress and chair batches (CS_CONV_CFG sweep, profiles/r3t_conv_cfg_sweep.txt):
+      // the shapes with the smallest LDS footprint win -- 64 x 64 (32 KB, 5 workgroups per CU) for Cout = 64 n
+      // (304 vs 347 us for 4 x 1 x 2 on the stride-2 64 -> 64 layers, 477 vs 525 at stride 1), 32 x 128 (40 KB) for
+      // Cout = 128 n (374 - 394 vs 446 us for 2 x 2 x 2): the kernel is limited by how many workgroups hide each
+      // other's barriers, prologues and epilogues, not by the MFMAs a DMA instruction feeds
+      (void)t128;
+      (void)t64;
       if (cout % 128 == 0)
-        cfg = t128 * (cout / 128) >= 512 ? 414 : t64 * (cout / 128) >= 256 ? 222 : 141;
+        cfg = 141;
       else if (cout % 64 == 0)
-        cfg = t128 * (cout / 64) >= 512 ? 412 : 221;
+        cfg = 221;
       else
         cfg = 411;
     }
