@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
     thr[g] = t;
   };
   const char* gimg = reinterpret_cast<const char*>(img + (int64_t)wk.t0 * KNF_PITCH) + lane * 16;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   for (int lab = lab_lo; lab <= lab_hi; ++lab) {
     int t_lo = 0, t_hi = wk.tn;
     if (use_labels) {
@@ -686,29 +687,46 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
     float thr_eff[KNF_NG];
 #pragma unroll
     for (int g = 0; g < KNF_NG; ++g) thr_eff[g] = (!use_labels || want[g] == lab) ? thr[g] : -INFINITY;
-    auto issue_stage = [&](int b, int base) {
+    // (LDS-DMA as inline asm + |t|^2 / row ids loaded before it and stored after the stage's compute: see k_topk_f16)
+    auto issue_dma = [&](int b, int base) {
       const char* gp = gimg + (int64_t)base * (KNF_PITCH * 2);
 #pragma unroll
       for (int i = 0; i < (STAGE_KIB + 3) / 4; ++i) {
         const int piece = wave + 4 * i;
-        if (piece < STAGE_KIB)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024),
-                                           (__attribute__((address_space(3))) void*)(lds + b * STAGE_BYTES + piece * 1024),
-                                           16, 0, 0);
+        if (piece < STAGE_KIB) lds_dma16(gp + piece * 1024, lds_base + b * STAGE_BYTES + piece * 1024);
       }
-      if (tid < KNF_ROWS) {  // |t|^2 and row ids; rows past the label's range can never be hit
+    };
+    auto load_rows = [&](int base, float& tn, int32_t& ti) {   // unconditional (clamped) loads
+      int r = base + (tid % KNF_ROWS);
+      r = r > t_hi - 1 ? t_hi - 1 : r;
+      r = r < t_lo ? t_lo : r;
+      tn = tn32[wk.t0 + r];
+      ti = ti32[wk.t0 + r];
+    };
+    auto store_rows = [&](int b, int base, float tn, int32_t ti) {
+      if (tid < KNF_ROWS) {  // rows past the label's range can never be hit
         const bool ok = base + tid < t_hi;
-        tn_s[b][tid] = ok ? tn32[wk.t0 + base + tid] : INFINITY;
-        ti_s[b][tid] = ok ? ti32[wk.t0 + base + tid] : 0x7fffffff;
+        tn_s[b][tid] = ok ? tn : INFINITY;
+        ti_s[b][tid] = ok ? ti : 0x7fffffff;
       }
     };
     __syncthreads();  // the previous label pass may still read the buffers
-    issue_stage(0, t_lo);
+    {
+      float tn0;
+      int32_t ti0;
+      load_rows(t_lo, tn0, ti0);
+      issue_dma(0, t_lo);
+      store_rows(0, t_lo, tn0, ti0);
+    }
     int buf = 0;
     for (int base = t_lo; base < t_hi; base += KNF_ROWS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (base + KNF_ROWS < t_hi) issue_stage(buf ^ 1, base + KNF_ROWS);
+      const bool more = base + KNF_ROWS < t_hi;
+      float tn_next;
+      int32_t ti_next;
+      load_rows(base + KNF_ROWS, tn_next, ti_next);
+      if (more) issue_dma(buf ^ 1, base + KNF_ROWS);
 #pragma unroll 1
       for (int t = 0; t < KNF_ROWS / 32; ++t) {
         if (base + 32 * t >= t_hi) break;  // whole tile past the range (block-uniform)
@@ -748,6 +766,7 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
           }
         }
       }
+      if (more) store_rows(buf ^ 1, base + KNF_ROWS, tn_next, ti_next);
       buf ^= 1;
     }
   }
@@ -1273,25 +1292,41 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
     bi[j] = 0x7fffffff;
   }
   const char* gimg = reinterpret_cast<const char*>(ximg) + lane * 16;
-  auto issue_stage = [&](int b, int64_t base) {
+  // A stage = the catalog image (LDS-DMA, written as inline asm: behind the builtin form hipcc waits vmcnt(0)
+  // in front of the first ds_read that follows, i.e. for the stage it has just issued "one ahead" -- lds_dma16,
+  // common.h) + the |x|^2 of its rows (a plain load, issued BEFORE the DMAs and stored to LDS AFTER the current
+  // stage is computed: hipcc's wait for it is then the only wait in the loop body and the DMAs have landed by then).
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  auto issue_dma = [&](int b, int64_t base) {
     const char* gp = gimg + base * PITCH_B;
 #pragma unroll
     for (int i = 0; i < (STAGE_PIECES + 7) / 8; ++i) {
       const int piece = wave + 8 * i;  // wave-uniform
       // (the last piece of a 64.5-KiB stage is half a KiB: the upper lanes sit it out)
       if (piece < STAGE_PIECES && piece * 1024 + lane * 16 < STAGE_BYTES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + piece * 1024),
-                                         (__attribute__((address_space(3))) void*)(lds + b * STAGE_PITCH + piece * 1024),
-                                         16, 0, 0);
+        lds_dma16(gp + piece * 1024, lds_base + b * STAGE_PITCH + piece * 1024);
     }
-    if (tid < ROWS) tn_s[b * ROWS + tid] = base + tid < xe ? (float)xn[base + tid] : INFINITY;
   };
-  if (xb < xe) issue_stage(0, xb);
+  auto load_norm = [&](int64_t base) {   // unconditional (clamped) load: a load under a condition is waited for at once
+    int64_t r = base + (tid % ROWS);
+    if (r > xe - 1) r = xe - 1;
+    return (float)xn[r < xb ? xb : r];
+  };
+  auto store_norm = [&](int b, int64_t base, float v) {
+    if (tid < ROWS) tn_s[b * ROWS + tid] = base + tid < xe ? v : INFINITY;
+  };
+  if (xb < xe) {
+    const float v0 = load_norm(xb);
+    issue_dma(0, xb);
+    store_norm(0, xb, v0);
+  }
   int buf = 0;
   for (int64_t base = xb; base < xe; base += ROWS) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (base + ROWS < xe) issue_stage(buf ^ 1, base + ROWS);
+    const bool more = base + ROWS < xe;
+    const float v_next = load_norm(base + ROWS);
+    if (more) issue_dma(buf ^ 1, base + ROWS);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1338,6 +1373,7 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
         }
       }
     }
+    if (more) store_norm(buf ^ 1, base + ROWS, v_next);
     buf ^= 1;
   }
   if (my_q < nq) {
