@@ -421,11 +421,11 @@ __global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nb
   row[o] = (int32_t)o;
 }
 
-// Row order of a SMALL map (<= SORT_SMALL_MAX rows: the coarse levels of a batch) in one launch: bitonic sort
+// Row order of a SMALL map (<= SORT_SMALL_MAX rows: the coarsest level of a batch) in one launch: bitonic sort
 // of (key << 32 | row) in LDS by one workgroup.  hipcub's radix sort takes a block-sort + merge path of 5 - 8
 // launches for such sizes (55 launches per chair step over the ten maps of a batch).  Any order of equal keys
 // is fine for the convolution; (key, row) pairs are distinct, so the result is also deterministic.
-constexpr int SORT_SMALL_MAX = 16384;
+constexpr int SORT_SMALL_MAX = 4096;   // (16 384 rows take one workgroup 150 us: hipcub wins from ~8 k rows on)
 __global__ __launch_bounds__(1024) void k_sort_small(const uint32_t* __restrict__ key, int n, int npow2,
                                                      uint32_t* __restrict__ key_sorted, int32_t* __restrict__ rowlist) {
   extern __shared__ unsigned long long sk[];

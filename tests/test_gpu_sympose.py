@@ -163,3 +163,44 @@ def test_real_gate_opens_and_a_symmetric_hypothesis_wins(gpu, oracle_native):
     mirror = [[0, 3, 2, 1], [3, 2, 1, 0], [2, 1, 0, 3], [1, 0, 3, 2]]
     assert any(w in mirror for w in winners) and any(len(w) == 4 and w not in mirror for w in winners)
     assert [1, 0] in winners and [0, 1] in winners
+
+
+def test_table_shape_c830_label_mix_matches_oracle(gpu, oracle_native):
+    """BASELINE.json configs[2] in shape: a C = 830 catalog with the symmetry-label histogram of the reference's
+    table label file (233 x 1, 422 x 2, 7 x 3, 128 x 4, 40 x 12: 72 % of the CADs take the K = 4 + mirror path),
+    queries retrieved top-1 against all 830 descriptors and registered with sym_pose -- embed, retrieve and
+    register through the product path, then every hypothesis of every pair against the oracle.  Smaller clouds
+    (3 000 points) and 2 000 RANSAC iterations keep the CPU side in seconds; the gate is forced as in the bench."""
+    from corsair_amd import harness, registration as R, synth
+    from oracle import native, post
+
+    C, Q, max_iter = 830, 12, 2000
+    hist = {1: 233, 2: 422, 3: 7, 4: 128, 12: 40}
+    labels = np.concatenate([np.full(n, l, np.int32) for l, n in hist.items()])
+    labels = labels[np.random.default_rng(2).permutation(C)]
+    cfg = harness.Config(ransac_max_iter=max_iter)
+    sd, emb = synth.make_state_dicts(31)
+    pipe = harness.Pipeline(sd, emb, device=gpu, config=cfg)
+    cat = pipe.embed_clouds([synth.make_cloud(c, 15000)[:3000] for c in range(C)])
+    q_cad = [3, 77, 150, 222, 301, 415, 498, 555, 640, 701, 777, 829]
+    qs = pipe.embed_clouds([synth.apply_pose(synth.make_cloud(c, 15000)[12000:], synth.random_pose(900 + i, max_trans=0.0))
+                            for i, c in enumerate(q_cad)])
+    top = pipe.retrieve(qs.desc, cat.desc, 1)[:, 0].cpu().numpy()
+    want_top = np.argsort(native.dist2_matrix(qs.desc.cpu().numpy(), cat.desc.cpu().numpy()), axis=1, kind="stable")[:, 0]
+    assert np.array_equal(top, want_top)
+    cads = cat.gather(top)
+    syms = labels[top]
+    assert (syms >= 2).sum() >= 4 and (syms < 2).sum() >= 1          # both K = 2 and K = 4 + mirror run
+    ids = [(2 * i, 2 * i + 1) for i in range(Q)]
+    res = pipe.register(qs, cads, syms, anchor_ids=ids, force_gate=True)
+    F0, X0, F1, X1 = (t.cpu().numpy() for t in (qs.F, qs.origin, cads.F, cads.origin))
+    n_hyp = 0
+    for p in range(Q):
+        a0, a1 = qs.offsets[p], qs.offsets[p + 1]
+        b0, b1 = cads.offsets[p], cads.offsets[p + 1]
+        want = post.sym_pose(F0[a0:a1], X0[a0:a1], F1[b0:b1], X1[b0:b1], int(syms[p]), cfg.k_nn, cfg.max_corr, 0,
+                             R.draw_anchors(a1 - a0, 100, ids[p][0]), R.draw_anchors(b1 - b0, 100, ids[p][1]),
+                             max_iter, cfg.ransac_confidence, force_gate=True, return_hyps=True)
+        hyps, _ = _compare_with_oracle(res, p, want, syms)
+        n_hyp += len(hyps)
+    assert res.n_problems == n_hyp
