@@ -38,6 +38,12 @@ __device__ __forceinline__ int floor_div(int a, int b) {
   return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
 }
 
+// floor(a / cell) * cell; cell a power of two (every tensor stride of the ResUNet): a mask instead of the
+// ~35-instruction run-time division
+__device__ __forceinline__ int floor_to_cell(int a, int cell) {
+  return (cell & (cell - 1)) == 0 ? (a & ~(cell - 1)) : floor_div(a, cell) * cell;
+}
+
 __global__ void k_fill_table(uint64_t* keys, int32_t* vals, uint64_t cap) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -55,9 +61,9 @@ __global__ void k_insert(const int32_t* __restrict__ coords, int64_t n, int cell
   if (i >= n) return;
   int b = coords[4 * i + 0], x = coords[4 * i + 1], y = coords[4 * i + 2], z = coords[4 * i + 3];
   if (cell > 1) {
-    x = floor_div(x, cell) * cell;
-    y = floor_div(y, cell) * cell;
-    z = floor_div(z, cell) * cell;
+    x = floor_to_cell(x, cell);
+    y = floor_to_cell(y, cell);
+    z = floor_to_cell(z, cell);
   }
   if (!coord_in_range(b, x, y, z)) {
     atomicOr(&status[0], 1);
@@ -84,9 +90,9 @@ __global__ void k_flag_first(const int32_t* __restrict__ coords, int64_t n, int 
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   int b = coords[4 * i + 0];
-  int x = floor_div(coords[4 * i + 1], cell) * cell;
-  int y = floor_div(coords[4 * i + 2], cell) * cell;
-  int z = floor_div(coords[4 * i + 3], cell) * cell;
+  int x = floor_to_cell(coords[4 * i + 1], cell);
+  int y = floor_to_cell(coords[4 * i + 2], cell);
+  int z = floor_to_cell(coords[4 * i + 3], cell);
   int32_t v = hash_lookup(keys, vals, mask, pack_key(b, x, y, z));
   flag[i] = (v == (int32_t)i) ? 1 : 0;
 }
@@ -98,9 +104,9 @@ __global__ void k_emit_strided(const int32_t* __restrict__ coords, int64_t n, in
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n || !flag[i]) return;
   int b = coords[4 * i + 0];
-  int x = floor_div(coords[4 * i + 1], cell) * cell;
-  int y = floor_div(coords[4 * i + 2], cell) * cell;
-  int z = floor_div(coords[4 * i + 3], cell) * cell;
+  int x = floor_to_cell(coords[4 * i + 1], cell);
+  int y = floor_to_cell(coords[4 * i + 2], cell);
+  int z = floor_to_cell(coords[4 * i + 3], cell);
   int32_t o = pos[i];
   out_coords[4 * o + 0] = b;
   out_coords[4 * o + 1] = x;
@@ -209,12 +215,17 @@ __global__ void k_segment_max(const int32_t* __restrict__ seg, int n_batch, int*
 // SLOTS = table size: 24576 (144 KB, one workgroup per CU: the stride-1 maps of 15 k-voxel samples), 8192
 // (48 KB, three per CU) or 2048 (12 KB) for the coarser levels, picked on the host from the mean sample size;
 // a sample that does not fit its table is flagged and goes through the global table like any other overflow.
+// ushift: log2(unit) when the in-map's tensor stride is a power of two (1, 2, 4, 8: every level of the ResUNet),
+// else -1.  The probe loop divides by `unit` six times per probe; as run-time integer divisions (~35 VALU
+// instructions each) they WERE the kernel: 174 -> see DESIGN 7c us per stride-1 map of the stress batch.
 template <int SLOTS, int NT>
 __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     const int32_t* __restrict__ in_coords, const int32_t* __restrict__ in_seg,
-    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int step,
+    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int ushift, int step,
     int sign, int32_t* __restrict__ nbr, unsigned long long* __restrict__ pair_count,
     int* __restrict__ fallback) {
+  auto udiv = [&](int v) { return ushift >= 0 ? v >> ushift : v / unit; };          // v >= 0
+  auto umult = [&](int v) { return ushift >= 0 ? (v & (unit - 1)) == 0 : v % unit == 0; };
   constexpr int LDS_SLOTS = SLOTS;
   constexpr int LDS_MAX_ROWS = SLOTS / 8 * 5;   // load factor <= 0.625
   __shared__ uint32_t keys[LDS_SLOTS];
@@ -261,16 +272,16 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
   }
   __syncthreads();
   const int mx = bmin[0], my = bmin[1], mz = bmin[2];
-  const int ex = i1 > i0 ? (bmax[0] - mx) / unit : 0, ey = i1 > i0 ? (bmax[1] - my) / unit : 0,
-            ez = i1 > i0 ? (bmax[2] - mz) / unit : 0;
+  const int ex = i1 > i0 ? udiv(bmax[0] - mx) : 0, ey = i1 > i0 ? udiv(bmax[1] - my) : 0,
+            ez = i1 > i0 ? udiv(bmax[2] - mz) : 0;
   if (ex > 1023 || ey > 1023 || ez > 1023 || i1 - i0 > LDS_MAX_ROWS) {
     if (tid == 0) fallback[b] = 1;
     return;
   }
   for (int i = i0 + tid; i < i1; i += NT) {
-    const uint32_t key = (uint32_t)((in_coords[4 * i + 1] - mx) / unit) |
-                         ((uint32_t)((in_coords[4 * i + 2] - my) / unit) << 10) |
-                         ((uint32_t)((in_coords[4 * i + 3] - mz) / unit) << 20);
+    const uint32_t key = (uint32_t)udiv(in_coords[4 * i + 1] - mx) |
+                         ((uint32_t)udiv(in_coords[4 * i + 2] - my) << 10) |
+                         ((uint32_t)udiv(in_coords[4 * i + 3] - mz) << 20);
     uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
     while (true) {
       const uint32_t old = atomicCAS(&keys[slot], LDS_EMPTY, key);
@@ -292,8 +303,8 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     const int y = out_coords[4 * o + 2] + sign * dy * step - my;
     const int z = out_coords[4 * o + 3] + sign * dz * step - mz;
     int32_t v = -1;
-    if (x >= 0 && y >= 0 && z >= 0 && x % unit == 0 && y % unit == 0 && z % unit == 0) {
-      const int cx = x / unit, cy = y / unit, cz = z / unit;
+    if (x >= 0 && y >= 0 && z >= 0 && umult(x) && umult(y) && umult(z)) {
+      const int cx = udiv(x), cy = udiv(y), cz = udiv(z);
       if (cx <= ex && cy <= ey && cz <= ez) {
         const uint32_t key = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
         uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
@@ -747,6 +758,12 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
       if (fb.p) {
         unsigned long long* const cnt_p = reinterpret_cast<unsigned long long*>(fb.p);
         int* const fb_p = fb.p + 2;
+        const int ts_in = in->tensor_stride;
+        int ushift = -1;
+        if (ts_in > 0 && (ts_in & (ts_in - 1)) == 0) {
+          ushift = 0;
+          while ((1 << ushift) < ts_in) ++ushift;
+        }
         int slices = 512 / (nb > 0 ? nb : 1);
         if (slices < 1) slices = 1;
         if (slices > 8) slices = 8;
@@ -758,15 +775,15 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
           if (small_tables && need <= 2048 / 8 * 5)
             hipLaunchKernelGGL((k_build_nbr_lds<2048, 256>), dim3((unsigned)slices, (unsigned)nb), dim3(256), 0, s,
                                in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
           else if (small_tables && need <= 8192 / 8 * 5)
             hipLaunchKernelGGL((k_build_nbr_lds<8192, 512>), dim3((unsigned)slices, (unsigned)nb), dim3(512), 0, s,
                                in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
           else
             hipLaunchKernelGGL((k_build_nbr_lds<LDS_SLOTS_MAX, 1024>), dim3((unsigned)slices, (unsigned)nb), dim3(1024),
                                0, s, in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, step, sign, km->d_nbr, cnt_p, fb_p);
+                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
           hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, out->d_coords,
                              out_m->d_seg, step, sign, in->d_keys, in->d_vals, in->capacity - 1,
                              km->d_nbr, cnt_p, fb_p);
