@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     int64_t n_out, const float* __restrict__ in, int ld_in, unsigned in_bytes, int cin, const float* __restrict__ w, int cout,
     unsigned w_bytes, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out, int ld_out,
-    unsigned long long* __restrict__ trace) {
+    unsigned long long* __restrict__ trace, int rev_order) {
   using C = ConvDmaCfg<RG, CG, NT>;
   constexpr int TM = C::TM, TN = C::TN;
   static_assert(RG * CG == 4, "4 waves");
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   const int cg = wave % CG;
   const int half = lane >> 5;
   const int rl = lane & 31;
-  const int64_t row0 = (int64_t)blockIdx.x * TM;
+  // workgroups take the tiles from the END of the tiling order first: the Gray rank puts the groups with the most
+  // offsets last, and heaviest-first leaves the cheap tiles for the ragged end of the launch (CS_CONV_FWD_ORDER=1: front first)
+  const int64_t row0 = (int64_t)(rev_order ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * TM;
   const int n0 = blockIdx.y * TN;
   const int cchunks = cin / 32;
 
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
   // everything of a tile that comes from memory is REQUESTED here (plain / scalar loads) and used much later
   auto load_tile = [&](int ti, Tile& t) {
     const bool ok = ti < n_tiles;
-    const int64_t row0 = (int64_t)(ok ? ti : 0) * TM;
+    const int64_t row0 = (int64_t)(ok ? n_tiles - 1 - ti : 0) * TM;   // heaviest tiles (end of the tiling order) first
     const int64_t tr = row0 + rg * 32 + rl;
     const int64_t trc = tr < n_out ? tr : 0;
     const int32_t o = rowlist ? rowlist[trc] : (int32_t)trc;       // (unconditional load)
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
     int32_t orow[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) orow[i] = __shfl(cur.my_o, (i & 3) + 8 * (i >> 2) + 4 * half);
-    const int64_t row0 = (int64_t)ti * TM;
+    const int64_t row0 = (int64_t)(n_tiles - 1 - ti) * TM;
     const int32_t o_safe = rowlist ? rowlist[row0] : (int32_t)row0;
     float res[NT][16];
 #pragma unroll
@@ -1200,13 +1202,13 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     const dim3 grid((unsigned)ceil_div(n_out, 32 * RG), (unsigned)(cout / (32 * NT * CG)));                     \
     if (trace)                                                                                                  \
       hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, true, true>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
-                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace, rev_order); \
     else if (nbr_t)                                                                                             \
       hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, true, false>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
-                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace, rev_order); \
     else                                                                                                        \
       hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, false, false>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
-                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace); \
+                         ld_in, in_bytes, cin, d_w, cout, w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, trace, rev_order); \
   } while (0)
     // CS_CONV_TRACE=1: per-wave phase cycles of this launch, summed and printed (diagnostics; synchronises)
     unsigned long long* trace = nullptr;
@@ -1217,6 +1219,7 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     }
     // (measured neutral: the registers the tile prefetch holds cost the resident workgroup per CU that it was meant
     // to make unnecessary -- 221: 72 -> 109 VGPRs; DESIGN 7c.  Off unless CS_CONV_PERSIST=1.)
+    const int rev_order = !(getenv("CS_CONV_FWD_ORDER") && getenv("CS_CONV_FWD_ORDER")[0] == '1');
     const bool persist = !trace && getenv("CS_CONV_PERSIST") && getenv("CS_CONV_PERSIST")[0] == '1';
     int cfg = dma_cfg;
     const int64_t t128 = ceil_div(n_out, 128), t64 = ceil_div(n_out, 64);

@@ -66,7 +66,7 @@ def test_conv_bit_exact(gpu, oracle_native, cin, cout):
     assert got.shape == (n, cout) and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("cfg", ["411", "412", "414", "221", "222", "141", "old", "persist", "persist411"])
+@pytest.mark.parametrize("cfg", ["411", "412", "414", "221", "222", "141", "old", "persist", "persist411", "front"])
 def test_conv_every_tile_shape_bit_exact(gpu, oracle_native, monkeypatch, cfg):
     """Every tile shape of the LDS-DMA kernel (CS_CONV_CFG=<row groups><column groups><32-column
     accumulators per wave>; shapes a layer's Cout does not allow fall back to the default choice) and
@@ -78,6 +78,8 @@ def test_conv_every_tile_shape_bit_exact(gpu, oracle_native, monkeypatch, cfg):
 
     if cfg == "old":
         monkeypatch.setenv("CS_CONV_DMA", "0")
+    elif cfg == "front":                     # tiles taken from the front of the tiling order (default: from the end)
+        monkeypatch.setenv("CS_CONV_FWD_ORDER", "1")
     elif cfg.startswith("persist"):          # persistent workgroups with next-tile prefetch (k_conv_dma_p)
         monkeypatch.setenv("CS_CONV_PERSIST", "1")
         if cfg != "persist":
