@@ -1317,10 +1317,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     ~Event() {
       if (e) (void)hipEventDestroy(e);
     }
-  } round_done, front_done[2];
+  } round_done, front_done[2], hyp_done[2];
   CS_HIP_CHECK(hipEventCreateWithFlags(&round_done.e, hipEventDisableTiming));
   CS_HIP_CHECK(hipEventCreateWithFlags(&front_done[0].e, hipEventDisableTiming));
   CS_HIP_CHECK(hipEventCreateWithFlags(&front_done[1].e, hipEventDisableTiming));
+  CS_HIP_CHECK(hipEventCreateWithFlags(&hyp_done[0].e, hipEventDisableTiming));
+  CS_HIP_CHECK(hipEventCreateWithFlags(&hyp_done[1].e, hipEventDisableTiming));
   // A round = front half (hypotheses, f16 rows, prefilter: independent of the carried best) + back
   // half (survivors, exact counts, scans: the sequential RANSAC state).  The front half of round i+1
   // is enqueued on a second, low-priority stream before the host waits for round i, so it fills the
@@ -1329,6 +1331,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // built from the state one round earlier: finished problems cost a few empty workgroups.
   const char* env_ov = getenv("CS_RANSAC_OVERLAP");
   hipStream_t side = (env_ov && env_ov[0] == '0') ? nullptr : side_stream();
+  // ... and the hypotheses of a side-stream front half go to a THIRD stream: those of round i+2 are enqueued when round i
+  // is known (their buffers, one set per parity, are free then) and run UNDER the prefilter of round i+1 instead of
+  // behind it on the same stream (f64 vector work beside f16 matrix work).  CS_RANSAC_HYP_STREAM=0: one side stream.
+  const char* env_hs = getenv("CS_RANSAC_HYP_STREAM");
+  hipStream_t side_hyp = (side && !(env_hs && env_hs[0] == '0')) ? side_stream(1) : nullptr;
   // an error return must not hand the scratch buffers back to the pool while the side stream still uses
   // them; on the normal path the final wait on the main stream is already ordered behind its events
   struct SideDrain {
@@ -1337,7 +1344,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     ~SideDrain() {
       if (st && !clean) (void)hipStreamSynchronize(st);
     }
-  } side_drain{side};
+  } side_drain{side}, side_hyp_drain{side_hyp};
   struct Front {
     int it0 = 0, b = 0, par = 0;
     bool pf = false, on_side = false;
@@ -1377,21 +1384,23 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       for (size_t i = 0; i < lists[x].size(); ++i) tab[(size_t)x * pslots + i] = lists[x][i];
     int32_t* xcd_prob = nullptr;
     XcdTab xtab;
+    // stream of the hypothesis kernels: the third stream for a prefiltered front half on the side stream
+    hipStream_t sh = (f.on_side && f.pf && side_hyp) ? side_hyp : st;
     if (pslots <= XCD_SLOTS) {
       memcpy(xtab.v, tab.data(), sizeof(int32_t) * 8 * pslots);
     } else {
       xcd_prob = xcd_buf.p + (size_t)par * 8 * n_prob;
-      (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, st);
+      (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, sh);
     }
     double* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
     {
-      ProfScope prof("ransac_hyp", st);
+      ProfScope prof("ransac_hyp", sh);
       const int htiles = (b + 255) / 256;
       if (ransac_n == 10)
-        hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
+        hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
                            pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
       else
-        hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, st, d_probs,
+        hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
                            pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
     }
     if (f.pf) {
@@ -1406,8 +1415,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (psplits > 16) psplits = 16;
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, st, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r,
+                         0, sh, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r,
                          psplits > 1 ? cnt_up_r : (int32_t*)nullptr);
+      if (sh != st) {   // the prefilter (side stream) follows the hypotheses (third stream)
+        (void)hipEventRecord(hyp_done[par].e, sh);
+        (void)hipStreamWaitEvent(st, hyp_done[par].e, 0);
+      }
       {
         ProfScope prof("ransac_pre", st);  // work units are added by the back half (state known there)
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
@@ -1579,6 +1592,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   CS_LAUNCH_CHECK();
   CS_HIP_CHECK(hipStreamSynchronize(s));
   side_drain.clean = true;
+  side_hyp_drain.clean = true;
   return CS_OK;
 }
 

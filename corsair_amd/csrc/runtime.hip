@@ -237,19 +237,23 @@ void prof_add_units(const char* name, double units) {
   g_prof_units[id] += units;
 }
 
-hipStream_t side_stream() {
-  thread_local hipStream_t st = nullptr;
+hipStream_t side_stream(int which) {
+  constexpr int N = 2;
+  thread_local hipStream_t st[N] = {nullptr, nullptr};
   thread_local int st_dev = -1;
+  if (which < 0 || which >= N) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (dev != st_dev) {  // first use (or the thread moved to another device: the old stream is abandoned)
+  if (dev != st_dev) {  // first use (or the thread moved to another device: the old streams are abandoned)
     st_dev = dev;
-    st = nullptr;
     int lo = 0, hi = 0;  // numerically greatest = lowest priority
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+    for (int i = 0; i < N; ++i) {
+      st[i] = nullptr;
+      if (hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, lo) != hipSuccess) st[i] = nullptr;
+    }
   }
-  return st;
+  return st[which];
 }
 
 ProfScope::~ProfScope() {
