@@ -37,6 +37,7 @@ def _declare(lib):
         "cs_coordmap_coords": (vp, [vp]),
         "cs_coordmap_free": (None, [vp]),
         "cs_kernelmap_build": (c_int, [vp, vp, c_int, c_int, vp, POINTER(vp)]),
+        "cs_kernelmap_build_many": (c_int, [c_int, POINTER(vp), POINTER(vp), POINTER(c_int), POINTER(c_int), vp, POINTER(vp)]),
         "cs_kernelmap_num_pairs": (c_int64, [vp]),
         "cs_kernelmap_rows": (c_int64, [vp]),
         "cs_kernelmap_table": (vp, [vp]),

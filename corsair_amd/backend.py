@@ -127,6 +127,23 @@ class KernelMap:
                                              ctypes.byref(out)))
         return cls(out.value, in_map, out_map, transposed)
 
+    @classmethod
+    def build_many(cls, specs):
+        """The kernel maps of one batch in one library call (cs_kernelmap_build_many: independent chains on up to three
+        streams).  specs: (in_map, out_map[, kernel_size[, transposed]]) tuples; returns the maps in that order."""
+        full = [(sp[0], sp[1], sp[2] if len(sp) > 2 else 3, bool(sp[3]) if len(sp) > 3 else False) for sp in specs]
+        n = len(full)
+        if n == 0:
+            return []
+        VP, CI = c_void_p * n, ctypes.c_int * n
+        ins = VP(*[sp[0]._h.value for sp in full])
+        outs = VP(*[sp[1]._h.value for sp in full])
+        ks = CI(*[int(sp[2]) for sp in full])
+        tr = CI(*[1 if sp[3] else 0 for sp in full])
+        kms = VP()
+        check(_lib.load().cs_kernelmap_build_many(n, ins, outs, ks, tr, stream_ptr(), kms))
+        return [cls(kms[i], full[i][0], full[i][1], full[i][3]) for i in range(n)]
+
     def export(self):
         """Canonical (k, in_row, out_row) int32 triples sorted by (k, out_row)."""
         n = max(self.num_pairs, 1)

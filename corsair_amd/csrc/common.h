@@ -83,6 +83,8 @@ void prof_add_units(const char* name, double units);
 // A second, lowest-priority stream of the calling thread (created on first use, lives as long as the
 // process) for work that may overlap the caller's stream; nullptr if it cannot be created.
 hipStream_t side_stream(int which = 0);
+void pool_defer_begin();
+void pool_defer_end();
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

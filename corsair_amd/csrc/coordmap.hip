@@ -703,8 +703,11 @@ void cs_coordmap_free(cs_coordmap* m) {
   delete m;
 }
 
-int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size,
-                       int transposed, void* stream, cs_kernelmap** km_out) {
+}  // extern "C"
+
+// one kernel map on stream `s` (the caller has announced its stream to the pool)
+static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int kernel_size, int transposed,
+                              hipStream_t s, cs_kernelmap** km_out) {
   CS_REQUIRE(in && out && km_out, CS_ERR_INVALID, "cs_kernelmap_build: NULL argument");
   *km_out = nullptr;
   CS_REQUIRE(kernel_size == 3 || kernel_size == 1, CS_ERR_UNSUPPORTED,
@@ -724,8 +727,6 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     step = out->tensor_stride;
     sign = -1;
   }
-  hipStream_t s = (hipStream_t)stream;
-  pool_use_stream(s);
   ProfScope prof("kmap", s);
   cs_kernelmap* km = new cs_kernelmap();
   km->n_out = out->n;
@@ -880,6 +881,93 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
     }
   }
   *km_out = km;
+  return CS_OK;
+}
+
+extern "C" {
+
+int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size,
+                       int transposed, void* stream, cs_kernelmap** km_out) {
+  pool_use_stream((hipStream_t)stream);
+  return kernelmap_build_on(in, out, kernel_size, transposed, (hipStream_t)stream, km_out);
+}
+
+// The kernel maps of a batch are independent chains of ~10-20 small dependent launches each (table, row keys, sort,
+// tiling-order tables): enqueued one behind the other they are bound by launch latency, not by the GPU.  Here map i
+// goes to stream i % N (the caller's, and N - 1 of the thread's side streams): every side stream starts behind the caller's
+// stream and the caller's stream continues behind all of them; scratch freed meanwhile is handed back to the pool
+// only after that join.  CS_KMAP_STREAMS=1: everything on the caller's stream.
+int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordmap* const* out, const int* kernel_size,
+                            const int* transposed, void* stream, cs_kernelmap** km_out) {
+  CS_REQUIRE(n >= 0 && (n == 0 || (in && out && kernel_size && transposed && km_out)), CS_ERR_INVALID,
+             "cs_kernelmap_build_many: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
+  for (int i = 0; i < n; ++i) km_out[i] = nullptr;
+  static const int n_streams = [] {
+    const char* e = getenv("CS_KMAP_STREAMS");
+    int v = e ? atoi(e) : 4;   // 2 / 3 / 4 / 5 streams: stress 6016 / 6201 / 6235 / 5608 clouds/s (the runtime maps streams to 4 queues)
+    return v < 1 ? 1 : (v > 5 ? 5 : v);
+  }();
+  hipStream_t st[5] = {s, nullptr, nullptr, nullptr, nullptr};
+  for (int k = 1; k < n_streams; ++k) st[k] = side_stream(k - 1);
+  int ns = 1;
+  while (ns < n_streams && st[ns]) ++ns;
+  if (ns == 1 || n < 2) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], s, &km_out[i]);
+      if (rc != CS_OK) {
+        for (int j = 0; j < i; ++j) { cs_kernelmap_free(km_out[j]); km_out[j] = nullptr; }
+        return rc;
+      }
+    }
+    return CS_OK;
+  }
+  // per-sample segments of the coordinate maps are made lazily by the first map that needs them: make them on the
+  // caller's stream before the streams fork
+  for (int i = 0; i < n; ++i) {
+    CS_REQUIRE(in[i] && out[i], CS_ERR_INVALID, "cs_kernelmap_build_many: NULL coordinate map");
+    if (kernel_size[i] == 3 && getenv("CS_KMAP_GLOBAL") == nullptr) {
+      (void)ensure_segments(const_cast<cs_coordmap*>(in[i]), s);
+      (void)ensure_segments(const_cast<cs_coordmap*>(out[i]), s);
+    }
+  }
+  struct Ev {
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) (void)hipEventDestroy(e); }
+  } fork, join[5];
+  CS_HIP_CHECK(hipEventCreateWithFlags(&fork.e, hipEventDisableTiming));
+  CS_HIP_CHECK(hipEventRecord(fork.e, s));
+  for (int k = 1; k < ns; ++k) {
+    CS_HIP_CHECK(hipEventCreateWithFlags(&join[k].e, hipEventDisableTiming));
+    CS_HIP_CHECK(hipStreamWaitEvent(st[k], fork.e, 0));
+  }
+  pool_defer_begin();
+  int rc = CS_OK;
+  for (int i = 0; i < n && rc == CS_OK; ++i) rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], st[i % ns], &km_out[i]);
+  // join (also on the error path: the side streams may hold work that reads scratch of this call)
+  hipError_t je = hipSuccess;
+  for (int k = 1; k < ns; ++k) {
+    hipError_t e1 = hipEventRecord(join[k].e, st[k]);
+    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, join[k].e, 0);
+    if (e1 != hipSuccess) {
+      (void)hipStreamSynchronize(st[k]);
+      je = e1;
+    }
+  }
+  if (rc != CS_OK || je != hipSuccess) {
+    for (int i = 0; i < n; ++i) {
+      if (km_out[i]) cs_kernelmap_free(km_out[i]);
+      km_out[i] = nullptr;
+    }
+    pool_defer_end();
+    if (rc == CS_OK) {
+      set_error("cs_kernelmap_build_many: joining the streams failed: %s", hipGetErrorString(je));
+      rc = CS_ERR_HIP;
+    }
+    return rc;
+  }
+  pool_defer_end();
   return CS_OK;
 }
 

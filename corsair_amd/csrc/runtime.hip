@@ -46,6 +46,10 @@ struct ThreadCache {
   }
 };
 static thread_local ThreadCache t_cache;
+// pool_defer_begin .. pool_defer_end: blocks freed in between change hands only at the end (a call that runs its kernels on
+// several streams joins them on the caller's stream first: the cache is ordered against ONE stream)
+static thread_local bool t_defer = false;
+static thread_local std::vector<std::pair<size_t, void*>> t_deferred;
 static thread_local hipStream_t t_stream = nullptr;
 static thread_local bool t_stream_set = false;
 
@@ -121,7 +125,17 @@ void pool_free(void* p) {
   }
   // ours: later work of this thread is enqueued behind whatever still uses the block (same stream, or a
   // stream this thread drained when it switched: pool_use_stream)
-  t_cache.free_[b.cls].push_back(p);
+  if (t_defer)
+    t_deferred.emplace_back(b.cls, p);
+  else
+    t_cache.free_[b.cls].push_back(p);
+}
+
+void pool_defer_begin() { t_defer = true; }
+void pool_defer_end() {
+  t_defer = false;
+  for (const auto& d : t_deferred) t_cache.free_[d.first].push_back(d.second);
+  t_deferred.clear();
 }
 
 void pool_stats(unsigned long long out[3]) {
@@ -238,8 +252,8 @@ void prof_add_units(const char* name, double units) {
 }
 
 hipStream_t side_stream(int which) {
-  constexpr int N = 2;
-  thread_local hipStream_t st[N] = {nullptr, nullptr};
+  constexpr int N = 4;
+  thread_local hipStream_t st[N] = {nullptr, nullptr, nullptr, nullptr};
   thread_local int st_dev = -1;
   if (which < 0 || which >= N) return nullptr;
   int dev = 0;

@@ -52,17 +52,13 @@ class BatchMaps:
         self.c2 = self.c1.stride(2)
         self.c4 = self.c2.stride(2)
         self.c8 = self.c4.stride(2)
-        K = B.KernelMap.build
-        self.s1 = K(self.c1, self.c1)
-        self.s1_s2 = K(self.c1, self.c2)
-        self.s2 = K(self.c2, self.c2)
-        self.s2_s4 = K(self.c2, self.c4)
-        self.s4 = K(self.c4, self.c4)
-        self.s4_s8 = K(self.c4, self.c8)
-        self.s8 = K(self.c8, self.c8)
-        self.s8_s4_T = K(self.c8, self.c4, transposed=True)
-        self.s4_s2_T = K(self.c4, self.c2, transposed=True)
-        self.s2_s1_T = K(self.c2, self.c1, transposed=True)
+        c1, c2, c4, c8 = self.c1, self.c2, self.c4, self.c8
+        names = ("s1", "s1_s2", "s2", "s2_s4", "s4", "s4_s8", "s8", "s8_s4_T", "s4_s2_T", "s2_s1_T")
+        specs = [(c1, c1), (c1, c2), (c2, c2), (c2, c4), (c4, c4), (c4, c8), (c8, c8),
+                 (c8, c4, 3, True), (c4, c2, 3, True), (c2, c1, 3, True)]
+        # one call: the ten maps are independent chains of small launches, built on three streams inside the library
+        for name, km in zip(names, B.KernelMap.build_many(specs)):
+            setattr(self, name, km)
 
     def total_pairs(self):
         return {n: getattr(self, n).num_pairs for n in

@@ -82,6 +82,12 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
                        int transposed, void* stream, cs_kernelmap** km);
 /* cs_kernelmap_build only enqueues work on `stream`; the pair count reaches the host behind it and
  * cs_kernelmap_num_pairs waits for that copy the first time it is asked (then it is cached). */
+/* The n maps of one batch (MinkowskiEngine builds them lazily, one per convolution, through the coordinate manager:
+ * model/resunet.py:163-237 is what asks for them): the same maps as n calls of cs_kernelmap_build, built as independent
+ * chains on several streams that fork from and join `stream` inside the call (CS_KMAP_STREAMS=1..5, default 4).
+ * On failure no map is returned (km[i] = NULL for all i). */
+int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordmap* const* out, const int* kernel_size,
+                            const int* transposed, void* stream, cs_kernelmap** km);
 int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km);
 int64_t cs_kernelmap_rows(const cs_kernelmap* km);
 const int32_t* cs_kernelmap_table(const cs_kernelmap* km);

@@ -115,6 +115,31 @@ def test_resunet_forward_bit_exact(gpu, oracle_native):
     assert np.array_equal(g.cpu().numpy(), want_g)
 
 
+def test_kernel_maps_build_many_equals_single_builds(gpu):
+    """cs_kernelmap_build_many (ten independent chains on three streams inside one call) returns exactly the maps of ten
+    cs_kernelmap_build calls: same neighbour tables, same pair counts; twice in a row (the second call reuses the
+    scratch the first handed back after its join)."""
+    from corsair_amd import backend as B
+
+    coords, _, _, _ = make_batch([11, 12, 13, 14], n_points=6000)
+    g = torch.from_numpy(coords).to(gpu)
+    c1 = B.CoordMap.create(g, 1)
+    c2 = c1.stride(2)
+    c4 = c2.stride(2)
+    c8 = c4.stride(2)
+    specs = [(c1, c1), (c1, c2), (c2, c2), (c2, c4), (c4, c4), (c4, c8), (c8, c8),
+             (c8, c4, 3, True), (c4, c2, 3, True), (c2, c1, 3, True)]
+    single = [B.KernelMap.build(*sp) for sp in specs]
+    for _ in range(2):
+        many = B.KernelMap.build_many(specs)
+        assert len(many) == len(single)
+        for a, b in zip(single, many):
+            assert a.n_out == b.n_out and a.n_in == b.n_in and a.transposed == b.transposed
+            assert a.num_pairs == b.num_pairs
+            assert torch.equal(a.table(), b.table())
+    assert B.KernelMap.build_many([]) == []
+
+
 def test_kernel_maps_lds_path_with_fallback_samples(gpu):
     """LDS-built kernel maps: a batch mixing an ordinary sample, one too large for the LDS table
     (> 15 360 voxels), one with a bounding box wider than 1023 cells and an empty batch index; the
