@@ -895,44 +895,58 @@ __global__ __launch_bounds__(256) void k_conv_stem(const int32_t* __restrict__ n
                                                    const float* __restrict__ residual, int ld_res, int relu,
                                                    float* __restrict__ out, int ld_out) {
   static_assert(COUT == 32, "one lane half per row parity");
-  __shared__ float xs[4][64][28];   // pitch 28: the broadcast reads below are conflict-free anyway
-  __shared__ unsigned ms[4][64];
+  __shared__ __attribute__((aligned(16))) float xs[4][64][28];   // 112-B rows: seven 16-B reads, broadcast (conflict-free)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
   {
-    // every load is unconditional (absent neighbours / rows past the end read row 0 and are masked out):
+    // every load is unconditional (absent neighbours / rows past the end read row 0 and are zeroed afterwards):
     // a per-element "load or not" makes hipcc wait for each of the 27 gathers in turn
     const bool live = base + lane < n_out;
     const int64_t o = live ? base + lane : n_out - 1;
-    unsigned m = 0;
     int32_t src[27];
-    float x[27];
+    float x[28];
 #pragma unroll
     for (int k = 0; k < 27; ++k) src[k] = nbr[o * 27 + k];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      m |= (live && src[k] >= 0 ? 1u : 0u) << k;
-      x[k] = in[(int64_t)(src[k] >= 0 ? src[k] : 0) * ld_in];
-    }
+    for (int k = 0; k < 27; ++k) x[k] = in[(int64_t)(src[k] >= 0 ? src[k] : 0) * ld_in];
+    // an absent offset contributes fma(0, w, acc) = acc: the chain of the present offsets, in order, like the oracle
+    // (the accumulator starts at +0 and a sum of products with +0 can never turn it into -0)
 #pragma unroll
-    for (int k = 0; k < 27; ++k) xs[wave][lane][k] = x[k];
-    ms[wave][lane] = m;
+    for (int k = 0; k < 27; ++k) x[k] = (live && src[k] >= 0) ? x[k] : 0.f;
+    x[27] = 0.f;
+    float4* row = reinterpret_cast<float4*>(&xs[wave][lane][0]);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) row[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
   }
   __syncthreads();
   const int co = lane & 31;
-  float wr[27];
+  float wr[28];
 #pragma unroll
   for (int k = 0; k < 27; ++k) wr[k] = w[k * COUT + co];
-  for (int r = lane >> 5; r < 64; r += 2) {
-    const int64_t o = base + r;
-    if (o >= n_out) break;
-    const unsigned m = ms[wave][r];
-    float acc = 0.f;
+  wr[27] = 0.f;
+  // two rows per step (two independent fma chains in flight per lane)
+  for (int r = lane >> 5; r < 64; r += 4) {
+    const int64_t o0 = base + r, o1 = o0 + 2;
+    if (o0 >= n_out) break;
+    const float4* row0 = reinterpret_cast<const float4*>(&xs[wave][r][0]);
+    const float4* row1 = reinterpret_cast<const float4*>(&xs[wave][r + 2][0]);
+    float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
-      if ((m >> k) & 1u) acc = __fmaf_rn(xs[wave][r][k], wr[k], acc);   // absent offsets are skipped like the oracle
-    const float* res_row = residual ? residual + o * ld_res : nullptr;
-    out[o * ld_out + co] = epilogue(acc, co, scale, shift, res_row, relu);
+    for (int q = 0; q < 7; ++q) {
+      const float4 v0 = row0[q], v1 = row1[q];
+      acc0 = __fmaf_rn(v0.x, wr[4 * q], acc0);
+      acc1 = __fmaf_rn(v1.x, wr[4 * q], acc1);
+      acc0 = __fmaf_rn(v0.y, wr[4 * q + 1], acc0);
+      acc1 = __fmaf_rn(v1.y, wr[4 * q + 1], acc1);
+      acc0 = __fmaf_rn(v0.z, wr[4 * q + 2], acc0);
+      acc1 = __fmaf_rn(v1.z, wr[4 * q + 2], acc1);
+      if (q < 6) {
+        acc0 = __fmaf_rn(v0.w, wr[4 * q + 3], acc0);
+        acc1 = __fmaf_rn(v1.w, wr[4 * q + 3], acc1);
+      }
+    }
+    out[o0 * ld_out + co] = epilogue(acc0, co, scale, shift, residual ? residual + o0 * ld_res : nullptr, relu);
+    if (o1 < n_out) out[o1 * ld_out + co] = epilogue(acc1, co, scale, shift, residual ? residual + o1 * ld_res : nullptr, relu);
   }
 }
 
