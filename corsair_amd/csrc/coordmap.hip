@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -364,6 +365,60 @@ static int ensure_segments(cs_coordmap* m, hipStream_t s) {
   return CS_OK;
 }
 
+// The same for several maps at once: TWO host round trips in total (last batch index of every map; the grouping
+// flags of every map) instead of two per map -- the four coordinate maps of a ResUNet batch cost eight otherwise.
+static int ensure_segments_many(cs_coordmap* const* maps, int n, hipStream_t s) {
+  std::vector<cs_coordmap*> todo;
+  for (int i = 0; i < n; ++i) {
+    cs_coordmap* m = maps[i];
+    if (!m || m->seg_state != 0) continue;
+    if (std::find(todo.begin(), todo.end(), m) != todo.end()) continue;
+    m->seg_state = -1;  // unavailable unless everything below succeeds
+    if (m->n > 0) todo.push_back(m);
+  }
+  if (todo.empty()) return CS_OK;
+  const size_t k = todo.size();
+  std::vector<int32_t> last_b(k, -1);
+  for (size_t i = 0; i < k; ++i)
+    CS_HIP_CHECK(download_async(&last_b[i], todo[i]->d_coords + 4 * (todo[i]->n - 1), sizeof(int32_t), s));
+  CS_HIP_CHECK(download_sync(s));
+  PoolBuf<int> flags(2 * k);
+  if (!flags.p) return CS_OK;
+  CS_HIP_CHECK(hipMemsetAsync(flags.p, 0, 2 * k * sizeof(int), s));
+  std::vector<int32_t*> seg(k, nullptr);
+  std::vector<int> h_flags(2 * k, 0);
+  for (size_t i = 0; i < k; ++i) {
+    cs_coordmap* m = todo[i];
+    if (last_b[i] < 0 || last_b[i] >= 65536) continue;
+    const int nb = last_b[i] + 1;
+    seg[i] = (int32_t*)pool_alloc((size_t)(nb + 1) * sizeof(int32_t));
+    if (!seg[i]) continue;
+    CS_HIP_CHECK(hipMemsetAsync(seg[i], 0, (size_t)(nb + 1) * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_segments, dim3((unsigned)ceil_div(m->n, 256)), dim3(256), 0, s, m->d_coords, m->n, nb, seg[i],
+                       flags.p + 2 * i);
+    hipLaunchKernelGGL(k_segment_max, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, s, seg[i], nb, flags.p + 2 * i);
+  }
+  hipError_t e = download_async(h_flags.data(), flags.p, 2 * k * sizeof(int), s);
+  if (e == hipSuccess) e = download_sync(s);
+  for (size_t i = 0; i < k; ++i) {
+    cs_coordmap* m = todo[i];
+    if (!seg[i]) continue;
+    if (e != hipSuccess || h_flags[2 * i]) {   // (not grouped by sample: global path)
+      pool_free(seg[i]);
+      continue;
+    }
+    m->d_seg = seg[i];
+    m->n_batch = last_b[i] + 1;
+    m->max_seg = h_flags[2 * i + 1];
+    m->seg_state = 1;
+  }
+  if (e != hipSuccess) {
+    set_error("ensure_segments_many: %s", hipGetErrorString(e));
+    return CS_ERR_HIP;
+  }
+  return CS_OK;
+}
+
 // Page-locked slots for the pair counts of kernel maps (one per live map, recycled on free).
 namespace {
 std::mutex g_slot_mu;
@@ -678,8 +733,8 @@ int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coord
                        in->d_coords, n, cell, flag.p, pos.p, m->d_keys, m->d_vals,
                        m->capacity - 1, m->d_coords);
     hipError_t e = hipGetLastError();
-    // flag/pos go back to the pool when this function returns; make sure the kernel is done
-    if (e == hipSuccess) e = download_sync(s);
+    // (no synchronisation: flag / pos go back to this thread's stream-ordered cache, whose next user is enqueued
+    // behind this kernel)
     if (e != hipSuccess) {
       cs_coordmap_free(m);
       set_error("cs_coordmap_stride: %s", hipGetErrorString(e));
@@ -925,12 +980,17 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
   }
   // per-sample segments of the coordinate maps are made lazily by the first map that needs them: make them on the
   // caller's stream before the streams fork
-  for (int i = 0; i < n; ++i) {
-    CS_REQUIRE(in[i] && out[i], CS_ERR_INVALID, "cs_kernelmap_build_many: NULL coordinate map");
-    if (kernel_size[i] == 3 && getenv("CS_KMAP_GLOBAL") == nullptr) {
-      (void)ensure_segments(const_cast<cs_coordmap*>(in[i]), s);
-      (void)ensure_segments(const_cast<cs_coordmap*>(out[i]), s);
+  {
+    std::vector<cs_coordmap*> need;
+    for (int i = 0; i < n; ++i) {
+      CS_REQUIRE(in[i] && out[i], CS_ERR_INVALID, "cs_kernelmap_build_many: NULL coordinate map");
+      if (kernel_size[i] == 3 && getenv("CS_KMAP_GLOBAL") == nullptr) {
+        need.push_back(const_cast<cs_coordmap*>(in[i]));
+        need.push_back(const_cast<cs_coordmap*>(out[i]));
+      }
     }
+    const int rc_seg = ensure_segments_many(need.data(), (int)need.size(), s);
+    if (rc_seg != CS_OK) return rc_seg;
   }
   struct Ev {
     hipEvent_t e = nullptr;
