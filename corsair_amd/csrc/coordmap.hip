@@ -820,7 +820,11 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
           ushift = 0;
           while ((1 << ushift) < ts_in) ++ushift;
         }
-        int slices = 512 / (nb > 0 ? nb : 1);
+        // workgroups per map: one per CU.  Every slice of a sample rebuilds the sample's table, so 512 workgroups (two
+        // rounds on 256 CUs with the 144-KB tables) build every table twice as often as 256 do for the same probes:
+        // stress 6 330 -> 6 430 clouds/s (CS_KMAP_WGS=128 / 256 / 512 / 1024: 6 235 / 6 430 / 6 330 / 6 312)
+        static const int slice_wgs = getenv("CS_KMAP_WGS") ? std::max(atoi(getenv("CS_KMAP_WGS")), 1) : 256;
+        int slices = slice_wgs / (nb > 0 ? nb : 1);
         if (slices < 1) slices = 1;
         if (slices > 8) slices = 8;
         e = hipMemsetAsync(fb.p, 0, sizeof(int) * (2 + nb), s);
