@@ -459,6 +459,7 @@ class StressWorkload:
     BATCHES_PER_STEP = 16
     TOPK_PER_STEP = 10240
     N_UNIQUE = 256
+    collective_in_step = True   # world > 1: the catalog-sharded top-k all-gathers queries and candidates
 
     def __init__(self, ctx):
         from corsair_amd import harness, synth
@@ -701,6 +702,10 @@ def main():
     # host thread on its own HIP stream, so the host work of one batch (index plumbing, the per-chunk
     # RANSAC control loop) overlaps the kernels of another.  D = 1 is the plain sequential loop.
     depth = max(1, min(args.pipeline, args.steps))
+    if depth > 1 and ctx.world > 1 and getattr(wl, "collective_in_step", False):
+        sys.stderr.write("[bench] --pipeline %d with %d ranks: this workload's step contains a collective, batches in flight "
+                         "would interleave the ranks' collectives; refusing\n" % (depth, ctx.world))
+        sys.exit(2)
     streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 3))]
 
     # worker threads are PERSISTENT (one single-thread executor each): the library caches scratch per host
@@ -781,7 +786,10 @@ def main():
     # times are not a roofline measurement there; profiling stays off.  The results must come out
     # identical to the sequential pass.
     overlap = None
-    if depth == 1 and args.steps >= 2 and not args.no_overlap_probe:
+    # (not with a collective inside the step on several ranks: the worker threads of a rank would issue their
+    # all-gathers in an order of their own and the ranks' collectives would no longer pair up)
+    collective_step = ctx.world > 1 and getattr(wl, "collective_in_step", False)
+    if depth == 1 and args.steps >= 2 and not args.no_overlap_probe and not collective_step:
         seq_results = {r[0]: r for r in wl.results}
         run_steps(0, min(3, args.warmup + args.steps), depth=3)   # untimed: every worker's first step (cold scratch)
         wl.results.clear()
