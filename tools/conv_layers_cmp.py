@@ -1,3 +1,4 @@
+"""Layer-by-layer comparison of two `tools/conv_layers.py` outputs: `python tools/conv_layers_cmp.py A.txt B.txt`."""
 import re, sys
 def parse(f):
     out=[]
