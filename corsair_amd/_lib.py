@@ -63,6 +63,9 @@ def _declare(lib):
         "cs_ransac_prefilter_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_knn_shortlist_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_l2_topk_stats": (None, [POINTER(c_uint64), c_int]),
+        "cs_topk_catalog_create": (c_int, [vp, c_int64, c_int, vp, POINTER(vp)]),
+        "cs_l2_topk_catalog": (c_int, [vp, c_int64, vp, c_int, vp, vp, c_int, vp]),
+        "cs_topk_catalog_free": (None, [vp]),
         "cs_symcut_fit": (c_int, [vp, c_int, vp, POINTER(c_int64), c_int, vp, c_int,
                                   POINTER(c_int32), c_int, c_int, c_int, vp, vp, vp, vp, vp]),
         "cs_symcut_labels": (c_int, [vp, POINTER(c_int64), c_int, POINTER(c_int32), vp, vp, vp]),

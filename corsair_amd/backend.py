@@ -266,12 +266,40 @@ def voxelize(xyz, offsets, voxel_size):
     return keep[:m], grid[:m], out_off
 
 
+class TopkCatalog:
+    """A fixed retrieval library (cs_topk_catalog): what the matrix-core top-k derives from the catalog rows is made once
+    and reused by every l2_topk against it.  Holds a reference to the descriptor tensor."""
+
+    def __init__(self, x):
+        self.x = _dev(x, torch.float32, "catalog").contiguous()
+        out = c_void_p()
+        check(_lib.load().cs_topk_catalog_create(ptr(self.x), self.x.shape[0], self.x.shape[1], stream_ptr(),
+                                                 ctypes.byref(out)))
+        self._h = out
+        self.shape = self.x.shape
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cs_topk_catalog_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def l2_topk(q, x, k, return_distance=False, squared=False):
-    """squared=True (with return_distance): the squared distances the ranking was made on (shard merges)."""
+    """x: catalog tensor or TopkCatalog.  squared=True (with return_distance): the squared distances the ranking was
+    made on (shard merges)."""
     q = _dev(q, torch.float32, "queries").contiguous()
-    x = _dev(x, torch.float32, "catalog").contiguous()
     idx = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
     dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=q.device) if return_distance else None
+    if isinstance(x, TopkCatalog):
+        if x.shape[1] != q.shape[1]:
+            raise ValueError("query and catalog dimensions differ")
+        check(_lib.load().cs_l2_topk_catalog(ptr(q), q.shape[0], x._h, k, ptr(idx), ptr(dist), 1 if squared else 0,
+                                             stream_ptr()))
+        return (idx, dist) if return_distance else idx
+    x = _dev(x, torch.float32, "catalog").contiguous()
     fn = _lib.load().cs_l2_topk_sq if squared else _lib.load().cs_l2_topk
     check(fn(ptr(q), q.shape[0], ptr(x), x.shape[0], q.shape[1], k, ptr(idx), ptr(dist), stream_ptr()))
     return (idx, dist) if return_distance else idx

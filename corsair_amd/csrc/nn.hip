@@ -997,6 +997,7 @@ __global__ void k_topk_init(unsigned long long* carry_d, int* carry_i, int64_t n
 // squared: write the squared distances the ranking was made on (cs_l2_topk_sq: shard merges compare exactly
 // what the kernels compared; two different squares can share one rounded square root)
 static thread_local int t_topk_squared = 0;
+static thread_local const ::cs_topk_catalog* t_topk_catalog = nullptr;   // set by cs_l2_topk_catalog around cs_l2_topk
 __global__ void k_topk_finish(const unsigned long long* carry_d, const int* carry_i, int64_t n,
                               int64_t* idx, double* dist, int squared) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1875,10 +1876,32 @@ static std::atomic<unsigned long long> g_topk_stats[2];
 
 // f16 matrix-core shortlist (d = 64 / 128 / 256 / 512, k <= 10), canonical re-score, verification, f64 path for
 // the queries that fail it.  Waits for the stream once (the number of such queries).
-static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
-                              int64_t* d_idx, double* d_dist, hipStream_t s) {
+// what topk_f16_shortlist makes of the catalog before it looks at a query: the padded f16 hi / lo image, the f64 row
+// norms and the bit pattern of their maximum.  A cs_topk_catalog keeps them across calls.
+struct TkfCatalog {
+  const _Float16* ximg = nullptr;
+  const double* xn = nullptr;
+  const unsigned* xmax = nullptr;
+};
+static int tkf_pitch(int d) { return (d / 16) * 32 + 8; }   // halfs per catalog image row (16 B of padding)
+static int64_t tkf_rows_padded(int64_t nx) { return ceil_div(nx, TKF_ROWS) * TKF_ROWS; }
+static int tkf_prepare_catalog(const float* d_x, int64_t nx, int d, _Float16* ximg, double* xn, unsigned* xmax,
+                               hipStream_t s) {
   const int dch = d / 16;
-  const int pitch_h = dch * 32 + 8;  // halfs per catalog image row (16 B of padding)
+  const int64_t n_pad = tkf_rows_padded(nx);
+  CS_HIP_CHECK(hipMemsetAsync(xmax, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn);
+  hipLaunchKernelGGL(k_max_bits, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, xn, nx, xmax);
+  hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(n_pad * dch, 256)), dim3(256), 0, s, d_x, nx, n_pad, d, 1.0f,
+                     ximg, tkf_pitch(d));
+  CS_LAUNCH_CHECK();
+  return CS_OK;
+}
+
+static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
+                              int64_t* d_idx, double* d_dist, hipStream_t s, const TkfCatalog* prepared = nullptr) {
+  const int dch = d / 16;
+  const int pitch_h = tkf_pitch(d);
   const int64_t qtiles = ceil_div(nq, TKF_QT);
   // catalog splits: one full round of workgroups.  d >= 256 leaves room for ONE workgroup per CU (2 x 65 KiB
   // of LDS stages): 256 slots, filled without a partial second round (every split adds 24 candidates per
@@ -1892,36 +1915,45 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   if (nsplit < 1) nsplit = 1;
   const int nlane = nsplit * 2;
   const int ncand = nlane * TKF_KK;  // <= 768 <= TKM_MERGE_CAP
-  const int64_t n_pad = ceil_div(nx, TKF_ROWS) * TKF_ROWS;
-  PoolBuf<_Float16> qimg((size_t)nq * dch * 32), ximg((size_t)n_pad * pitch_h);
-  PoolBuf<double> qn(nq), xn(nx);
-  PoolBuf<unsigned> xmax(1);
+  const int64_t n_pad = tkf_rows_padded(nx);
+  PoolBuf<_Float16> qimg((size_t)nq * dch * 32), ximg_own;
+  PoolBuf<double> qn(nq), xn_own;
+  PoolBuf<unsigned> xmax_own;
   PoolBuf<int> cand_i((size_t)nq * ncand), ci((size_t)nq * k), flagged((size_t)nq + 1);
   PoolBuf<float> tau((size_t)nq * nlane);
   PoolBuf<unsigned long long> cd((size_t)nq * k);
-  CS_REQUIRE(qimg.p && ximg.p && qn.p && xn.p && xmax.p && cand_i.p && ci.p && flagged.p && tau.p && cd.p,
+  TkfCatalog cat;
+  if (prepared) {
+    cat = *prepared;
+  } else {   // (no handle: the catalog is prepared for this call only)
+    ximg_own.alloc((size_t)n_pad * pitch_h);
+    xn_own.alloc((size_t)nx);
+    xmax_own.alloc(1);
+    CS_REQUIRE(ximg_own.p && xn_own.p && xmax_own.p, CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
+    const int rc0 = tkf_prepare_catalog(d_x, nx, d, ximg_own.p, xn_own.p, xmax_own.p, s);
+    if (rc0) return rc0;
+    cat.ximg = ximg_own.p;
+    cat.xn = xn_own.p;
+    cat.xmax = xmax_own.p;
+  }
+  CS_REQUIRE(qimg.p && qn.p && cand_i.p && ci.p && flagged.p && tau.p && cd.p,
              CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
   int* const n_flagged = flagged.p + nq;
-  CS_HIP_CHECK(hipMemsetAsync(xmax.p, 0, sizeof(unsigned), s));
   CS_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
-  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, d_x, nx, d, xn.p);
-  hipLaunchKernelGGL(k_max_bits, dim3((unsigned)ceil_div(nx, 256)), dim3(256), 0, s, xn.p, nx, xmax.p);
   hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(nq * dch, 256)), dim3(256), 0, s, d_q, nq, nq, d,
                      -2.0f, qimg.p, dch * 32);
-  hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(n_pad * dch, 256)), dim3(256), 0, s, d_x, nx, n_pad,
-                     d, 1.0f, ximg.p, pitch_h);
   const dim3 grid((unsigned)qtiles, (unsigned)nsplit);
   const int terms = dch == 32 ? 2 : 3;
-  int rc = dch == 32   ? launch_topk_f16<32, 2, 32>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
-           : dch == 16 ? launch_topk_f16<16, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
-           : dch == 8  ? launch_topk_f16<8, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p)
-                       : launch_topk_f16<4, 3, 64>(grid, s, qimg.p, nq, ximg.p, nx, xn.p, nsplit, cand_i.p, tau.p);
+  int rc = dch == 32   ? launch_topk_f16<32, 2, 32>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+           : dch == 16 ? launch_topk_f16<16, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+           : dch == 8  ? launch_topk_f16<8, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+                       : launch_topk_f16<4, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p);
   if (rc) return rc;
   hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand, k,
                      cd.p, ci.p);
   hipLaunchKernelGGL(k_tkf_verify, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, cd.p, k, nq, tau.p,
-                     nlane, qn.p, xmax.p, d, terms, flagged.p, n_flagged);
+                     nlane, qn.p, cat.xmax, d, terms, flagged.p, n_flagged);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p, ci.p,
                      nq * k, d_idx, d_dist, t_topk_squared);
   CS_LAUNCH_CHECK();
@@ -1945,6 +1977,65 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
     CS_LAUNCH_CHECK();
   }
   return CS_OK;
+}
+
+// ---- catalog handle -------------------------------------------------------------------------------------------
+// The catalog of a retrieval run is fixed (evaluation.py:264-283 embeds the CAD library once and ranks every scan
+// against it); what the f16 path makes of it -- image, norms, their maximum: 4.2 ms per call at 10^6 x 256 -- is made
+// once here and reused by every cs_l2_topk_catalog call.  Shapes the f16 path does not take keep only the pointer.
+struct cs_topk_catalog {
+  const float* d_x = nullptr;
+  int64_t nx = 0;
+  int d = 0;
+  _Float16* ximg = nullptr;
+  double* xn = nullptr;
+  unsigned* xmax = nullptr;
+};
+
+int cs_topk_catalog_create(const float* d_x, int64_t nx, int d, void* stream, cs_topk_catalog** out) {
+  CS_REQUIRE(d_x && out, CS_ERR_INVALID, "cs_topk_catalog_create: NULL argument");
+  *out = nullptr;
+  CS_REQUIRE(d >= 1 && nx >= 1 && nx < (1LL << 31), CS_ERR_INVALID, "cs_topk_catalog_create: bad shape (%lld x %d)",
+             (long long)nx, d);
+  hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
+  cs_topk_catalog* c = new cs_topk_catalog();
+  c->d_x = d_x;
+  c->nx = nx;
+  c->d = d;
+  const bool f16_shape = (d == 64 || d == 128 || d == 256 || d == 512) && nx >= TKF_ROWS;
+  if (f16_shape) {
+    c->ximg = (_Float16*)pool_alloc((size_t)tkf_rows_padded(nx) * tkf_pitch(d) * sizeof(_Float16));
+    c->xn = (double*)pool_alloc((size_t)nx * sizeof(double));
+    c->xmax = (unsigned*)pool_alloc(sizeof(unsigned));
+    int rc = (c->ximg && c->xn && c->xmax) ? tkf_prepare_catalog(d_x, nx, d, c->ximg, c->xn, c->xmax, s) : CS_ERR_HIP;
+    if (rc) {
+      if (rc == CS_ERR_HIP && !(c->ximg && c->xn && c->xmax)) set_error("cs_topk_catalog_create: allocation failed");
+      cs_topk_catalog_free(c);
+      return rc;
+    }
+  }
+  *out = c;
+  return CS_OK;
+}
+
+void cs_topk_catalog_free(cs_topk_catalog* c) {
+  if (!c) return;
+  pool_free(c->ximg);
+  pool_free(c->xn);
+  pool_free(c->xmax);
+  delete c;
+}
+
+int cs_l2_topk_catalog(const float* d_q, int64_t nq, const cs_topk_catalog* cat, int k, int64_t* d_idx, double* d_dist,
+                       int squared, void* stream) {
+  CS_REQUIRE(cat, CS_ERR_INVALID, "cs_l2_topk_catalog: NULL catalog");
+  t_topk_catalog = cat;
+  t_topk_squared = squared ? 1 : 0;
+  const int rc = cs_l2_topk(d_q, nq, cat->d_x, cat->nx, cat->d, k, d_idx, d_dist, stream);
+  t_topk_squared = 0;
+  t_topk_catalog = nullptr;
+  return rc;
 }
 
 void cs_l2_topk_stats(uint64_t out[2], int reset) {
@@ -1980,7 +2071,17 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   const bool f16_shape = (d == 64 || d == 128 || d == 256 || d == 512) && k <= TKF_KK - 2 && nx >= TKF_ROWS;
   const bool want16 = force ? (force[0] == '1' && force[1] == '6') : big;
   const bool want64 = force ? (force[0] == '1' || force[0] == '6') : big;
-  if (want16 && f16_shape) return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);
+  if (want16 && f16_shape) {
+    TkfCatalog pre;
+    const cs_topk_catalog* c = t_topk_catalog;
+    const bool have = c && c->ximg && c->d_x == d_x && c->nx == nx && c->d == d;
+    if (have) {
+      pre.ximg = c->ximg;
+      pre.xn = c->xn;
+      pre.xmax = c->xmax;
+    }
+    return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s, have ? &pre : nullptr);
+  }
   if (want64 && k <= TKM_KK - 2) return topk_f64_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);
   // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
   int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);

@@ -168,6 +168,15 @@ int cs_l2_topk_sq(const float* d_q, int64_t nq, const float* d_x, int64_t nx, in
  * f16 matrix cores, exact re-score, verification): {queries that took it, queries recomputed by the
  * f64 path because the verification failed (ties at the k-th neighbour)}. */
 void cs_l2_topk_stats(uint64_t out[2], int reset);
+/* A retrieval run ranks every scan against ONE fixed library (evaluation.py:264-283: `lib_desc` is embedded once,
+ * utils/retrieval.py:139-177 ranks against it): the handle keeps what the matrix-core path derives from the catalog
+ * (f16 image, f64 norms) across calls; results are those of cs_l2_topk / cs_l2_topk_sq (squared != 0) on the same
+ * arrays.  The caller keeps d_x alive and unchanged for the life of the handle. */
+typedef struct cs_topk_catalog cs_topk_catalog;
+int cs_topk_catalog_create(const float* d_x, int64_t nx, int d, void* stream, cs_topk_catalog** out);
+int cs_l2_topk_catalog(const float* d_q, int64_t nq, const cs_topk_catalog* catalog, int k, int64_t* d_idx,
+                       double* d_dist, int squared, void* stream);
+void cs_topk_catalog_free(cs_topk_catalog* catalog);
 
 /* ------------------------------------------------------------------------------------------
  * Batched feature k-NN.  Replaces find_knn_cpu / KDTree(feat1).query(feat0, k)

@@ -404,6 +404,38 @@ def test_l2_topk_f16_shortlist_path_bit_exact(gpu, oracle_native, monkeypatch, n
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
 
 
+@pytest.mark.parametrize("nq,nx,d,k,force", [(37, 5000, 256, 10, "16"), (130, 20000, 64, 10, "16"), (290, 6000, 512, 10, "16"),
+                                             (50, 652, 256, 1, None), (5, 40, 256, 3, "16"), (20, 3000, 48, 5, "16")])
+def test_l2_topk_catalog_handle_equals_plain_calls(gpu, oracle_native, monkeypatch, nq, nx, d, k, force):
+    """cs_topk_catalog (image and norms of a fixed library made once) gives the ids and distances of cs_l2_topk /
+    cs_l2_topk_sq on the same arrays -- on the f16 path that uses the prepared pieces, on shapes that path does not take
+    (slab path, d not a multiple of 64, fewer rows than one stage) and for two different query sets against one handle --
+    and those are the oracle's."""
+    from corsair_amd import backend as B, synth
+
+    if force:
+        monkeypatch.setenv("CS_TOPK_MFMA", force)
+    x = synth.make_descriptors(nx, d, seed=32)
+    xd = torch.from_numpy(x).to(gpu)
+    cat = B.TopkCatalog(xd)
+    for seed in (31, 33):
+        q = synth.make_descriptors(nq, d, seed=seed)
+        qd = torch.from_numpy(q).to(gpu)
+        i0, d0 = B.l2_topk(qd, xd, k, True)
+        i1, d1 = B.l2_topk(qd, cat, k, True)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+        i2, s2 = B.l2_topk(qd, cat, k, True, squared=True)
+        i3, s3 = B.l2_topk(qd, xd, k, True, squared=True)
+        assert torch.equal(i2, i3) and torch.equal(s2, s3) and torch.equal(i2, i0)
+        assert torch.equal(B.l2_topk(qd, cat, k), i0)
+        d2 = oracle_native.dist2_matrix(q, x)
+        want = np.argsort(d2, axis=1, kind="stable")[:, :k]
+        assert np.array_equal(i1.cpu().numpy(), want)
+        assert np.array_equal(d1.cpu().numpy(), np.sqrt(np.take_along_axis(d2, want, 1)))
+    with pytest.raises(ValueError):
+        B.l2_topk(torch.zeros((2, d + 1), device=gpu), cat, 1)
+
+
 def test_l2_topk_f16_falls_back_on_ties_and_scales(gpu, oracle_native, monkeypatch):
     """600 copies of one catalog row: for the query next to it more rows tie at the k-th neighbour than
     the shortlist holds, the verification cannot succeed and the query is recomputed by the f64 path --

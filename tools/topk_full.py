@@ -1,7 +1,7 @@
 """BASELINE.json configs[4], second half at FULL contract size: top-10 of 10^6 queries against a 10^6
 catalog of row-normalised descriptors (Philox standard normal), 256-d (the reference's
-descriptor width) and 512-d (the width BASELINE.json names).  Queries go through cs_l2_topk in 16 slabs
-of 65 536; the catalog stays resident.  Prints one JSON object.
+descriptor width) and 512-d (the width BASELINE.json names).  Queries go through cs_l2_topk_catalog in 16 slabs
+of 65 536 against ONE catalog handle (image and norms made once); the catalog stays resident.  Prints one JSON object.
 
   python tools/topk_full.py [--dims 256 512] [--n 1000000] [--slab 65536]
 """
@@ -27,7 +27,8 @@ for d in args.dims:
         x[s:s + m] = torch.from_numpy(synth.make_descriptors(m, d, seed=4321 + i)).to(dev)
         q[s:s + m] = torch.from_numpy(synth.make_descriptors(m, d, seed=1234 + i)).to(dev)
     print("[topk_full] d=%d: descriptors generated in %.1fs" % (d, time.time() - t0), file=sys.stderr, flush=True)
-    B.l2_topk(q[:4096], x, 10)
+    cat = B.TopkCatalog(x)
+    B.l2_topk(q[:4096], cat, 10)
     torch.cuda.synchronize()
     st = (ctypes.c_uint64 * 2)()
     _lib.load().cs_l2_topk_stats(st, 1)
@@ -36,7 +37,7 @@ for d in args.dims:
     ok_sorted = True
     t0 = time.time()
     for s in range(0, args.n, args.slab):
-        i, dist = B.l2_topk(q[s:s + args.slab], x, 10, True)
+        i, dist = B.l2_topk(q[s:s + args.slab], cat, 10, True)
         idx[s:s + args.slab] = i
         first[s:s + args.slab] = dist[:, 0]
         ok_sorted = ok_sorted and bool((dist[:, 1:] >= dist[:, :-1]).all())
