@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   }
   // LDS read addresses: A piece j of this lane's row sits at slot j ^ swz -> base ^ (j << 4); the stage
   // buffer is toggled by adding +- STAGE_BYTES once per chunk
-  unsigned a_rd = lds_base + rg * 4096 + rl * 128 + (((rl >> 1) & 7) << 4);
+  unsigned a_rd = lds_base + rg * 4096 + rl * 128 + (((rl >> 1) & 7) << 4) + 4 * half;
   unsigned b_rd = lds_base + C::A_BYTES + (half * TN + cg * 32 * NT + rl) * 4;
   int buf = 0;
   unsigned long long t_start = 0, t_wait = 0, t_vm = 0, t_body = 0, n_chunk = 0, n_act = 0, t_pre = 0;
@@ -448,10 +448,14 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     if (TRACE) t2 = __builtin_amdgcn_s_memtime();
     const bool active = (mymask >> k) & 1u;
     // first fragment reads of this chunk: their latency runs under the address arithmetic below
-    float4 av[8];
+    // (each lane half reads ITS two channels of the 16-B slot -- 4 j + half and 4 j + 2 + half, one ds_read2_b32 --
+    // instead of the whole slot and a v_cndmask per MFMA: VALU instructions take the matrix pipe's cycles)
+    float2 av[8];
     float bv[16][NT];
     auto rd = [&](int j) {
-      av[j] = *reinterpret_cast<const float4*>(lds + ((a_rd ^ (unsigned)(j << 4)) - lds_base));
+      const float* ap = reinterpret_cast<const float*>(lds + ((a_rd ^ (unsigned)(j << 4)) - lds_base));
+      av[j].x = ap[0];
+      av[j].y = ap[2];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         bv[2 * j][t] = *reinterpret_cast<const float*>(lds + (b_rd - lds_base) + ((4 * j) * TN + t * 32) * 4);
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j + 2 < 8) rd(j + 2);
-        const float a0 = half ? av[j].y : av[j].x;
-        const float a1 = half ? av[j].w : av[j].z;
+        const float a0 = av[j].x;
+        const float a1 = av[j].y;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], acc[t], 0, 0, 0);
 #pragma unroll
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
     a_offsets(cur, s1, vo_n);
   };
   start_blocking();
-  unsigned a_rd = lds_base + rg * 4096 + rl * 128 + (((rl >> 1) & 7) << 4);
+  unsigned a_rd = lds_base + rg * 4096 + rl * 128 + (((rl >> 1) & 7) << 4) + 4 * half;
   unsigned b_rd = lds_base + C::A_BYTES + (half * TN + cg * 32 * NT + rl) * 4;
 
   f32x16 acc[NT];
@@ -751,10 +755,12 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const bool active = (cur.mymask >> k) & 1u;
-      float4 av[8];
+      float2 av[8];   // (this lane half's two channels of the slot: see k_conv_dma)
       float bv[16][NT];
       auto rd = [&](int j) {
-        av[j] = *reinterpret_cast<const float4*>(lds + ((a_rd ^ (unsigned)(j << 4)) - lds_base));
+        const float* ap = reinterpret_cast<const float*>(lds + ((a_rd ^ (unsigned)(j << 4)) - lds_base));
+        av[j].x = ap[0];
+        av[j].y = ap[2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           bv[2 * j][t] = *reinterpret_cast<const float*>(lds + (b_rd - lds_base) + ((4 * j) * TN + t * 32) * 4);
@@ -805,8 +811,8 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (j + 2 < 8) rd(j + 2);
-          const float a0 = half ? av[j].y : av[j].x;
-          const float a1 = half ? av[j].w : av[j].z;
+          const float a0 = av[j].x;
+          const float a1 = av[j].y;
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], acc[t], 0, 0, 0);
 #pragma unroll
