@@ -244,7 +244,6 @@ struct ConvDmaCfg {
 };
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
-constexpr unsigned DMA_OOB = 0x80000000u;   // byte offset no tensor reaches (the launcher checks): reads as zeros
 
 // raw buffer descriptor over [base, base + bytes): stride 0, offsets at or beyond `bytes` read as zero
 __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   auto a_offsets = [&](const int32_t (&src)[A_PIECES], unsigned (&vo)[A_PIECES]) {
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i)
-      vo[i] = (a_row_ok[i] && src[i] >= 0) ? (__umul24((unsigned)src[i], ld_in_b) + a_c4b[i]) : DMA_OOB;
+      vo[i] = __umul24((unsigned)src[i], ld_in_b) + a_c4b[i];   // absent = row n_in: past the descriptor's range
   };
   auto b_soff = [&](int k, int cc) { return (unsigned)(((k < K_END ? k : 0) * cin + cc * 32) * cout) * 4u; };
 
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(256) void k_conv_dma_p(
   auto a_offsets = [&](const Tile& t, const int32_t (&src)[A_PIECES], unsigned (&vo)[A_PIECES]) {
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i)
-      vo[i] = (t.a_row_ok[i] && src[i] >= 0) ? (__umul24((unsigned)src[i], ld_in_b) + a_c4b[i]) : DMA_OOB;
+      vo[i] = __umul24((unsigned)src[i], ld_in_b) + a_c4b[i];   // absent = row n_in: past the descriptor's range
   };
   auto b_soff = [&](int k, int cc) { return (unsigned)(((k < K_END ? k : 0) * cin + cc * 32) * cout) * 4u; };
 

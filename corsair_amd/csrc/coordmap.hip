@@ -524,12 +524,15 @@ __global__ __launch_bounds__(1024) void k_sort_small(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist,
                                                        const uint32_t* __restrict__ key_sorted, int64_t n_out, int kvol,
                                                        int32_t* __restrict__ nbr_sorted, uint32_t* __restrict__ gmask,
-                                                       int64_t n_groups_padded) {
+                                                       int64_t n_groups_padded, int32_t absent) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e < n_out * kvol) {
     const int64_t t = e / kvol;
     const int k = (int)(e - t * kvol);
-    nbr_sorted[e] = nbr[(int64_t)rowlist[t] * kvol + k];
+    // an absent neighbour is stored as row `absent` = n_in, ONE PAST the input tensor: the convolution turns entries
+    // into byte offsets with one multiply-add and the buffer descriptor's range check returns zeros for that row
+    const int32_t v = nbr[(int64_t)rowlist[t] * kvol + k];
+    nbr_sorted[e] = v < 0 ? absent : v;
   }
   if (e < n_groups_padded) {
     uint32_t m = 0;
@@ -930,7 +933,7 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
       return CS_ERR_HIP;
     }
     hipLaunchKernelGGL(k_sorted_tables, dim3((unsigned)ceil_div(n * km->kvol, 256)), dim3(256), 0, s, km->d_nbr,
-                       km->d_rowlist, key_sorted.p, n, km->kvol, km->d_nbr_sorted, km->d_gmask, n_groups);
+                       km->d_rowlist, key_sorted.p, n, km->kvol, km->d_nbr_sorted, km->d_gmask, n_groups, (int32_t)km->n_in);
     if (e2 == hipSuccess) e2 = hipGetLastError();
     // no synchronisation: the scratch returns to this thread's stream-ordered cache
     if (e2 != hipSuccess) {
