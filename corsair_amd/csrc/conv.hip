@@ -436,7 +436,11 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     t_start = __builtin_amdgcn_s_memtime();
     rt_loop0 = __builtin_amdgcn_s_memrealtime();
   }
-  while (k < K_END) {
+  // One chunk, accumulators in `src` before and in `dst` after it.  hipcc selects the first MFMA behind `if (active)`
+  // in its untied form (its SrcC has a second use on the skipping path) and, with ONE home for the accumulators, copies
+  // all 16 NT of them every chunk to feed it.  With two homes that alternate per chunk the untied MFMA IS the move;
+  // only a chunk the wave skips pays for a copy.
+  auto chunk = [&](f32x16 (&src)[NT], f32x16 (&dst)[NT]) __attribute__((always_inline)) {
     // the DMA of this chunk has landed (every wave waits for its own pieces, then the barrier) and every
     // wave is done reading the other buffer (it read it before arriving here)
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -484,10 +488,6 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const unsigned a_dst = a_lds + (buf ^ 1) * C::STAGE_BYTES, b_dst = b_lds + (buf ^ 1) * C::STAGE_BYTES;
     const unsigned a_so = __builtin_amdgcn_readfirstlane((unsigned)ncc * 128u);
     const unsigned b_so = __builtin_amdgcn_readfirstlane(b_soff(nk, ncc));
-    // (keeps the accumulators in ONE register tuple on both paths: without it hipcc moves all 16 NT of them
-    // into a second tuple and back around the MFMA block, 48 NT VALU moves per chunk)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
     if (active) {
       // one chunk on the matrix pipe.  Hand-placed software pipeline (the volatile DMA statements pin the order):
       // fragment reads run two steps ahead of their MFMAs, one DMA instruction of the next stage goes out
@@ -499,10 +499,11 @@ __global__ __launch_bounds__(256) void k_conv_dma(
         const float a0 = av[j].x;
         const float a1 = av[j].y;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
+          dst[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], j == 0 ? src[t] : dst[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[2 * j + 1][t], acc[t], 0, 0, 0);
+          dst[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[2 * j + 1][t], dst[t], 0, 0, 0);
         if (j < A_PIECES) {
           if (stage_a) buf_dma16(vo_n[j], srd_a, a_so, a_dst + j * 1024);
         } else if (j < A_PIECES + B_PIECES) {
@@ -510,6 +511,8 @@ __global__ __launch_bounds__(256) void k_conv_dma(
         }
       }
     } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dst[t] = src[t];
       if (stage_a) {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) buf_dma16(vo_n[i], srd_a, a_so, a_dst + i * 1024);
@@ -535,6 +538,18 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     nk = k2; ncc = cc2;
     k2 = k3; cc2 = cc3;
     buf ^= 1;
+  };
+  {
+    f32x16 acc_b[NT];
+    while (k < K_END) {
+      chunk(acc, acc_b);
+      if (k >= K_END) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = acc_b[t];
+        break;
+      }
+      chunk(acc_b, acc);
+    }
   }
   if (TRACE) {
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
