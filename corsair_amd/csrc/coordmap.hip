@@ -250,14 +250,12 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     // bounding box: per-thread, then per-wave (shuffles), then one LDS atomic per wave and axis
     // (one atomic per coordinate serialises ~27 k updates on six addresses: 85 us -> measured below)
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
-    // (a row is one aligned 16-B load: b, x, y, z)
     for (int i = i0 + tid; i < i1; i += NT) {
-      const int4 c = reinterpret_cast<const int4*>(in_coords)[i];
-      const int v3[3] = {c.y, c.z, c.w};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        lo[a] = min(lo[a], v3[a]);
-        hi[a] = max(hi[a], v3[a]);
+        const int v = in_coords[4 * i + 1 + a];
+        lo[a] = min(lo[a], v);
+        hi[a] = max(hi[a], v);
       }
     }
 #pragma unroll
@@ -282,8 +280,9 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     return;
   }
   for (int i = i0 + tid; i < i1; i += NT) {
-    const int4 c = reinterpret_cast<const int4*>(in_coords)[i];
-    const uint32_t key = (uint32_t)udiv(c.y - mx) | ((uint32_t)udiv(c.z - my) << 10) | ((uint32_t)udiv(c.w - mz) << 20);
+    const uint32_t key = (uint32_t)udiv(in_coords[4 * i + 1] - mx) |
+                         ((uint32_t)udiv(in_coords[4 * i + 2] - my) << 10) |
+                         ((uint32_t)udiv(in_coords[4 * i + 3] - mz) << 20);
     uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
     while (true) {
       const uint32_t old = atomicCAS(&keys[slot], LDS_EMPTY, key);
@@ -301,10 +300,9 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     const int o = s0 + t / 27;
     const int k = t - (t / 27) * 27;
     const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
-    const int4 oc = reinterpret_cast<const int4*>(out_coords)[o];
-    const int x = oc.y + sign * dx * step - mx;
-    const int y = oc.z + sign * dy * step - my;
-    const int z = oc.w + sign * dz * step - mz;
+    const int x = out_coords[4 * o + 1] + sign * dx * step - mx;
+    const int y = out_coords[4 * o + 2] + sign * dy * step - my;
+    const int z = out_coords[4 * o + 3] + sign * dz * step - mz;
     int32_t v = -1;
     if (x >= 0 && y >= 0 && z >= 0 && umult(x) && umult(y) && umult(z)) {
       const int cx = udiv(x), cy = udiv(y), cz = udiv(z);
