@@ -1054,16 +1054,29 @@ __global__ void k_segmax_init(unsigned* buf, int64_t n) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t < n) buf[t] = f2ord(-INFINITY);
 }
-__global__ void k_segmax(int64_t n, int c, const float* __restrict__ in, int ld_in,
-                         const int32_t* __restrict__ batch, int batch_ld, int n_batch,
-                         unsigned* obuf) {
-  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= n * c) return;
-  int64_t r = t / c;
-  int col = (int)(t - r * c);
-  int b = batch[r * batch_ld];
-  if (b < 0 || b >= n_batch) return;
-  atomicMax(&obuf[(int64_t)b * c + col], f2ord(in[r * ld_in + col]));
+// One atomic per RUN of rows of one sample (not one per row): a thread owns one column of a block
+// of SEGMAX_ROWS consecutive rows, keeps the running maximum while the batch index stays the same and flushes it when
+// it changes (rows grouped by sample, the usual case: 32 x fewer atomics; any other order is still correct).
+constexpr int SEGMAX_ROWS = 32;
+__global__ void k_segmax_runs(int64_t n, int c, const float* __restrict__ in, int ld_in,
+                              const int32_t* __restrict__ batch, int batch_ld, int n_batch, unsigned* obuf) {
+  const int col = blockIdx.y * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  const int64_t r0 = (int64_t)blockIdx.x * SEGMAX_ROWS;
+  const int64_t r1 = r0 + SEGMAX_ROWS < n ? r0 + SEGMAX_ROWS : n;
+  int cur = -1;
+  unsigned best = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const int b = batch[r * batch_ld];
+    if (b != cur) {
+      if (cur >= 0 && cur < n_batch) atomicMax(&obuf[(int64_t)cur * c + col], best);
+      cur = b;
+      best = 0;   // f2ord maps every float above 0: the first value of the run replaces it
+    }
+    const unsigned v = f2ord(in[r * ld_in + col]);
+    best = v > best ? v : best;
+  }
+  if (cur >= 0 && cur < n_batch && r1 > r0) atomicMax(&obuf[(int64_t)cur * c + col], best);
 }
 __global__ void k_segmax_fin(unsigned* buf, int64_t n) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1406,8 +1419,8 @@ int cs_segmented_max(int64_t n, int c, const float* d_in, int ld_in, const int32
   unsigned* obuf = reinterpret_cast<unsigned*>(d_out);
   hipLaunchKernelGGL(k_segmax_init, dim3((unsigned)ceil_div(on, 256)), dim3(256), 0, s, obuf, on);
   if (n > 0)
-    hipLaunchKernelGGL(k_segmax, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, s, n, c,
-                       d_in, ld_in, d_batch, batch_ld, n_batch, obuf);
+    hipLaunchKernelGGL(k_segmax_runs, dim3((unsigned)ceil_div(n, SEGMAX_ROWS), (unsigned)ceil_div(c, 256)), dim3(256), 0, s,
+                       n, c, d_in, ld_in, d_batch, batch_ld, n_batch, obuf);
   hipLaunchKernelGGL(k_segmax_fin, dim3((unsigned)ceil_div(on, 256)), dim3(256), 0, s, obuf, on);
   CS_LAUNCH_CHECK();
   return CS_OK;
