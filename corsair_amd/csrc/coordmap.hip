@@ -219,7 +219,10 @@ __global__ void k_segment_max(const int32_t* __restrict__ seg, int n_batch, int*
 // ushift: log2(unit) when the in-map's tensor stride is a power of two (1, 2, 4, 8: every level of the ResUNet),
 // else -1.  The probe loop divides by `unit` six times per probe; as run-time integer divisions (~35 VALU
 // instructions each) they WERE the kernel: 174 -> see DESIGN 7c us per stride-1 map of the stress batch.
-template <int SLOTS, int NT>
+// SYM (in map == out map, a submanifold convolution): row o has row i at offset k exactly when row i has row o at the
+// opposite offset 26 - k, and offset 13 is the row itself.  Only offsets 0..12 are probed; a hit writes both entries
+// (every entry has one writer), misses keep the -1 the table was filled with before the launch.
+template <int SLOTS, int NT, bool SYM>
 __global__ __launch_bounds__(NT) void k_build_nbr_lds(
     const int32_t* __restrict__ in_coords, const int32_t* __restrict__ in_seg,
     const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int ushift, int step,
@@ -295,10 +298,16 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
   }
   __syncthreads();
   int found_total = 0;
-  const int total = (s1 - s0) * 27;
+  constexpr int KP = SYM ? 14 : 27;   // offsets handled per row
+  const int total = (s1 - s0) * KP;
   for (int t = tid; t < total; t += NT) {
-    const int o = s0 + t / 27;
-    const int k = t - (t / 27) * 27;
+    const int o = s0 + t / KP;
+    const int k = t - (t / KP) * KP;
+    if (SYM && k == 13) {
+      nbr[(int64_t)o * 27 + 13] = o;
+      found_total += 1;
+      continue;
+    }
     const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
     const int x = out_coords[4 * o + 1] + sign * dx * step - mx;
     const int y = out_coords[4 * o + 2] + sign * dy * step - my;
@@ -320,8 +329,16 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
         }
       }
     }
-    nbr[(int64_t)o * 27 + k] = v;
-    found_total += v >= 0;
+    if (SYM) {
+      if (v >= 0) {
+        nbr[(int64_t)o * 27 + k] = v;
+        nbr[(int64_t)v * 27 + (26 - k)] = o;
+        found_total += 2;
+      }
+    } else {
+      nbr[(int64_t)o * 27 + k] = v;
+      found_total += v >= 0;
+    }
   }
   // block-level pair count: wave reduce, one atomic per wave
 #pragma unroll
@@ -835,18 +852,33 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
           // table size from the mean in-sample size (2.5x headroom; larger samples take the flagged path)
           const int64_t need = (in->n / (nb > 0 ? nb : 1)) * 5 / 2;
           static const bool small_tables = !(getenv("CS_KMAP_SMALL") && getenv("CS_KMAP_SMALL")[0] == '0');
-          if (small_tables && need <= 2048 / 8 * 5)
-            hipLaunchKernelGGL((k_build_nbr_lds<2048, 256>), dim3((unsigned)slices, (unsigned)nb), dim3(256), 0, s,
-                               in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
+          // submanifold map (same coordinate map on both sides, plain convolution): half of the probes
+          // (maps of >= 200 000 rows: below that the table fill and the scattered mirror writes cost what the probes
+          // save -- stress 7 217 -> 7 317 clouds/s, the 160 000-row maps of the chair batch unchanged either way)
+          // CS_KMAP_SYM=0 / 1: never / whatever the size (tests)
+          const char* env_sym = getenv("CS_KMAP_SYM");
+          const bool sym = in == out && !transposed && sign > 0 &&
+                           (env_sym ? env_sym[0] == '1' : km->n_out >= 200000);
+          if (sym) e = hipMemsetAsync(km->d_nbr, 0xff, (size_t)total * sizeof(int32_t), s);
+#define CS_NBR_LDS(SLOTS_, NT_)                                                                                          \
+  do {                                                                                                                    \
+    if (sym)                                                                                                              \
+      hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, true>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,      \
+                         in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg, in->tensor_stride, ushift, step, sign,   \
+                         km->d_nbr, cnt_p, fb_p);                                                                         \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, false>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,     \
+                         in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg, in->tensor_stride, ushift, step, sign,   \
+                         km->d_nbr, cnt_p, fb_p);                                                                         \
+  } while (0)
+          if (e != hipSuccess) {
+          } else if (small_tables && need <= 2048 / 8 * 5)
+            CS_NBR_LDS(2048, 256);
           else if (small_tables && need <= 8192 / 8 * 5)
-            hipLaunchKernelGGL((k_build_nbr_lds<8192, 512>), dim3((unsigned)slices, (unsigned)nb), dim3(512), 0, s,
-                               in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
+            CS_NBR_LDS(8192, 512);
           else
-            hipLaunchKernelGGL((k_build_nbr_lds<LDS_SLOTS_MAX, 1024>), dim3((unsigned)slices, (unsigned)nb), dim3(1024),
-                               0, s, in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg,
-                               in->tensor_stride, ushift, step, sign, km->d_nbr, cnt_p, fb_p);
+            CS_NBR_LDS(LDS_SLOTS_MAX, 1024);
+#undef CS_NBR_LDS
           hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, out->d_coords,
                              out_m->d_seg, step, sign, in->d_keys, in->d_vals, in->capacity - 1,
                              km->d_nbr, cnt_p, fb_p);

@@ -115,6 +115,27 @@ def test_resunet_forward_bit_exact(gpu, oracle_native):
     assert np.array_equal(g.cpu().numpy(), want_g)
 
 
+def test_kernel_maps_symmetric_probes_at_size(gpu, monkeypatch):
+    """A map large enough for the library to pick the symmetric build on its own (>= 200 000 rows) equals the map built
+    with every offset probed, entry for entry, and a forward over both gives the same features."""
+    from corsair_amd import backend as B, synth
+
+    clouds = [synth.make_cloud(c, 15000) for c in range(24)]
+    xyz = torch.from_numpy(np.concatenate(clouds)).to(gpu)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).tolist()
+    _, grid, _ = B.voxelize(xyz, off, 0.02)
+    c1 = B.CoordMap.create(grid, 1)
+    assert c1.n >= 200000
+    monkeypatch.setenv("CS_KMAP_SYM", "0")
+    full = B.KernelMap.build(c1, c1)
+    monkeypatch.delenv("CS_KMAP_SYM")
+    sym = B.KernelMap.build(c1, c1)
+    assert sym.num_pairs == full.num_pairs
+    assert torch.equal(sym.table(), full.table())
+    t = full.table()
+    assert bool((t[:, 13] == torch.arange(c1.n, device=gpu, dtype=torch.int32)).all())
+
+
 def test_kernel_maps_build_many_equals_single_builds(gpu):
     """cs_kernelmap_build_many (ten independent chains on three streams inside one call) returns exactly the maps of ten
     cs_kernelmap_build calls: same neighbour tables, same pair counts; twice in a row (the second call reuses the
@@ -140,10 +161,16 @@ def test_kernel_maps_build_many_equals_single_builds(gpu):
     assert B.KernelMap.build_many([]) == []
 
 
-def test_kernel_maps_lds_path_with_fallback_samples(gpu):
+@pytest.mark.parametrize("sym", [None, "1", "0"])
+def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, sym):
     """LDS-built kernel maps: a batch mixing an ordinary sample, one too large for the LDS table
     (> 15 360 voxels), one with a bounding box wider than 1023 cells and an empty batch index; the
-    flagged samples go through the global-table kernel.  Also: rows not grouped by sample."""
+    flagged samples go through the global-table kernel.  Also: rows not grouped by sample.
+    sym = "1": the submanifold maps (s1, s2, s4, s8) are built from half of the probes, a hit writing both mirrored
+    entries (the library does that by itself only for maps of >= 200 000 rows: see
+    test_kernel_maps_symmetric_probes_at_size)."""
+    if sym is not None:
+        monkeypatch.setenv("CS_KMAP_SYM", sym)
     from oracle import resunet as oref
     from oracle import sparse as osp
 
