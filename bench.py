@@ -309,7 +309,7 @@ class RegistrationWorkload:
             cad = q % C
             T = synth.random_pose(q, max_trans=0.0)
             pc = synth.make_cloud(cad, 15000)[15000 - cfg.n_points:]
-            self.q_clouds.append(synth.apply_pose(pc, T))
+            self.q_clouds.append(synth.apply_pose(pc, T, np.float64))   # apply_transform's f64: quantised in f64
             self.q_T.append(T)
             self.q_cad.append(cad)
         self.q_dev, self.q_off = [], []
@@ -410,7 +410,7 @@ class RegistrationWorkload:
         for pc in clouds:
             xyz, grid, _ = osp.quantize_cloud(pc, cfg.voxel_size)
             grids.append(grid)
-            origins.append(xyz)
+            origins.append(xyz.astype(np.float32))       # narrowed after the selection
         coords = osp.sparse_collate(grids)
         feats = np.ones((coords.shape[0], 1), np.float32)
         out, feat8, maps = oref.resunet_forward(self.sd, coords, feats)

@@ -50,6 +50,7 @@ def _declare(lib):
         "cs_segmented_max": (c_int, [c_int64, c_int, vp, c_int, vp, c_int, c_int, vp, vp]),
         "cs_instance_norm": (c_int, [c_int64, c_int, vp, c_int, vp, c_int, vp, vp, c_float, vp, c_int, vp]),
         "cs_voxelize": (c_int, [vp, POINTER(c_int64), c_int, c_double, vp, vp, POINTER(c_int64), vp]),
+        "cs_voxelize_f64": (c_int, [vp, POINTER(c_int64), c_int, c_double, vp, vp, POINTER(c_int64), vp]),
         "cs_l2_topk": (c_int, [vp, c_int64, vp, c_int64, c_int, c_int, vp, vp, vp]),
         "cs_l2_topk_sq": (c_int, [vp, c_int64, vp, c_int64, c_int, c_int, vp, vp, vp]),
         "cs_knn_feat": (c_int, [vp, POINTER(c_int64), vp, POINTER(c_int64), POINTER(c_int32),

@@ -250,17 +250,20 @@ def instance_norm(x, seg, weight=None, bias=None, eps=1e-8):
 
 
 def voxelize(xyz, offsets, voxel_size):
-    """cs_voxelize: xyz f32 [n,3] device, offsets host list.  Returns (keep_idx int64 [m],
-    grid int32 [m,4], out_offsets list)."""
-    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    """cs_voxelize / cs_voxelize_f64: xyz f32 or f64 [n,3] device, offsets host list.  The grid index is
+    floor(x / voxel) in the cloud's own type, like the reference's NumPy expression: f32 for the catalog
+    clouds (utils/Info/CADLib.py:106-121), f64 for posed queries (datasets/CategoryDataset.py:179-197,
+    evaluation-shapenet.py:97-119).  Returns (keep_idx int64 [m], grid int32 [m,4], out_offsets list)."""
+    f64 = torch.is_tensor(xyz) and xyz.dtype == torch.float64
+    xyz = _dev(xyz, torch.float64 if f64 else torch.float32, "xyz").contiguous()
     n = xyz.shape[0]
     nseg = len(offsets) - 1
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=xyz.device)
     grid = torch.empty((max(n, 1), 4), dtype=torch.int32, device=xyz.device)
     h_off = i64_array(offsets)
     h_out = (ctypes.c_int64 * (nseg + 1))()
-    check(_lib.load().cs_voxelize(ptr(xyz), h_off, nseg, float(voxel_size), ptr(keep), ptr(grid),
-                                  h_out, stream_ptr()))
+    fn = _lib.load().cs_voxelize_f64 if f64 else _lib.load().cs_voxelize
+    check(fn(ptr(xyz), h_off, nseg, float(voxel_size), ptr(keep), ptr(grid), h_out, stream_ptr()))
     out_off = [int(v) for v in h_out]
     m = out_off[-1]
     return keep[:m], grid[:m], out_off

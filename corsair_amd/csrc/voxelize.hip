@@ -2,8 +2,11 @@
 // return_index=True, return_maps_only=True) + the batch-index prepend of ME.utils.sparse_collate
 // (utils/Info/CADLib.py:106-121,148-178; datasets/CategoryDataset.py:179-197).
 // Same hash-insert machinery as the strided coordinate map: first point of every voxel wins,
-// kept indices ascending.  Grid index = floorf(x / voxel) evaluated in f32 exactly like the
-// reference's NumPy expression on its f32 clouds.
+// kept indices ascending.  Grid index = floor(x / voxel) evaluated in the cloud's OWN type, as NumPy
+// does: f32 clouds (the catalog side, utils/Info/CADLib.py:106-121: `f32 array / python float` is an f32
+// division by f32(voxel)) through cs_voxelize, f64 clouds (the query side: datasets/CategoryDataset.py:
+// 179-197 floors the f64 output of apply_transform, evaluation-shapenet.py:97-119 the f64 posed cloud;
+// the cast to f32 comes AFTER the selection there) through cs_voxelize_f64 with an IEEE f64 division.
 #include <hipcub/hipcub.hpp>
 
 #include <vector>
@@ -12,11 +15,24 @@
 
 namespace cs {
 
-__device__ __forceinline__ bool vox_key(const float* __restrict__ xyz, int64_t i, int seg,
-                                        float vs, uint64_t* key, int* g) {
-  g[0] = (int)floorf(xyz[3 * i + 0] / vs);
-  g[1] = (int)floorf(xyz[3 * i + 1] / vs);
-  g[2] = (int)floorf(xyz[3 * i + 2] / vs);
+// floor(x / vs) as an int, saturated so that a huge or non-finite quotient fails the range check
+// instead of wrapping in the conversion.
+__device__ __forceinline__ int vox_cell(float x, float vs) {
+  const float q = floorf(x / vs);
+  return q >= -65536.f && q <= 65536.f ? (int)q : 0x7fffffff;
+}
+__device__ __forceinline__ int vox_cell(double x, double vs) {
+  const double q = floor(x / vs);
+  return q >= -65536.0 && q <= 65536.0 ? (int)q : 0x7fffffff;
+}
+
+template <typename T>
+__device__ __forceinline__ bool vox_key(const T* __restrict__ xyz, int64_t i, int seg, T vs,
+                                        uint64_t* key, int* g) {
+  g[0] = vox_cell(xyz[3 * i + 0], vs);
+  g[1] = vox_cell(xyz[3 * i + 1], vs);
+  g[2] = vox_cell(xyz[3 * i + 2], vs);
+  if (g[0] == 0x7fffffff || g[1] == 0x7fffffff || g[2] == 0x7fffffff) return false;
   if (!coord_in_range(seg, g[0], g[1], g[2])) return false;
   *key = pack_key(seg, g[0], g[1], g[2]);
   return true;
@@ -31,8 +47,9 @@ __global__ void k_vox_fill(uint64_t* keys, int32_t* vals, uint64_t cap) {
   }
 }
 
-__global__ void k_vox_insert(const float* __restrict__ xyz, const int32_t* __restrict__ seg_of,
-                             int64_t n, float vs, uint64_t* keys, int32_t* vals, uint64_t mask,
+template <typename T>
+__global__ void k_vox_insert(const T* __restrict__ xyz, const int32_t* __restrict__ seg_of,
+                             int64_t n, T vs, uint64_t* keys, int32_t* vals, uint64_t mask,
                              int* status) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -54,8 +71,9 @@ __global__ void k_vox_insert(const float* __restrict__ xyz, const int32_t* __res
   }
 }
 
-__global__ void k_vox_flag(const float* __restrict__ xyz, const int32_t* __restrict__ seg_of,
-                           int64_t n, float vs, const uint64_t* __restrict__ keys,
+template <typename T>
+__global__ void k_vox_flag(const T* __restrict__ xyz, const int32_t* __restrict__ seg_of,
+                           int64_t n, T vs, const uint64_t* __restrict__ keys,
                            const int32_t* __restrict__ vals, uint64_t mask, int32_t* flag) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -70,17 +88,18 @@ __global__ void k_vox_flag(const float* __restrict__ xyz, const int32_t* __restr
   flag[i] = f;
 }
 
-__global__ void k_vox_emit(const float* __restrict__ xyz, const int32_t* __restrict__ seg_of,
-                           int64_t n, float vs, const int32_t* __restrict__ flag,
+template <typename T>
+__global__ void k_vox_emit(const T* __restrict__ xyz, const int32_t* __restrict__ seg_of,
+                           int64_t n, T vs, const int32_t* __restrict__ flag,
                            const int32_t* __restrict__ pos, int64_t* keep, int32_t* grid) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n || !flag[i]) return;
   const int32_t o = pos[i];
   keep[o] = i;
   grid[4 * o + 0] = seg_of[i];
-  grid[4 * o + 1] = (int)floorf(xyz[3 * i + 0] / vs);
-  grid[4 * o + 2] = (int)floorf(xyz[3 * i + 1] / vs);
-  grid[4 * o + 3] = (int)floorf(xyz[3 * i + 2] / vs);
+  grid[4 * o + 1] = vox_cell(xyz[3 * i + 0], vs);
+  grid[4 * o + 2] = vox_cell(xyz[3 * i + 1], vs);
+  grid[4 * o + 3] = vox_cell(xyz[3 * i + 2], vs);
 }
 
 __global__ void k_vox_segment_ids(const int64_t* __restrict__ off, int n_seg, int32_t* seg_of) {
@@ -100,14 +119,9 @@ __global__ void k_vox_offsets(const int64_t* __restrict__ off, int n_seg, int64_
   out_off[s] = i < n ? (int64_t)pos[i] : (n > 0 ? (int64_t)pos[n - 1] + flag[n - 1] : 0);
 }
 
-}  // namespace cs
-
-using namespace cs;
-
-extern "C" {
-
-int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
-                int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream) {
+template <typename T>
+static int voxelize_impl(const T* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
+                         int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream) {
   CS_REQUIRE(d_xyz && h_offsets && d_keep_idx && d_grid && h_out_offsets, CS_ERR_INVALID,
              "cs_voxelize: NULL argument");
   CS_REQUIRE(n_seg >= 1 && n_seg < 65536, CS_ERR_INVALID, "cs_voxelize: bad segment count");
@@ -124,7 +138,7 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
   if (n == 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
-  const float vs = (float)voxel_size;
+  const T vs = (T)voxel_size;
   uint64_t cap = 1024;
   while (cap < (uint64_t)(2 * n)) cap <<= 1;
   PoolBuf<uint64_t> keys(cap);
@@ -142,9 +156,9 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
   hipLaunchKernelGGL(k_vox_segment_ids,
                      dim3((unsigned)(ceil_div(seg_max > 0 ? seg_max : 1, 256)), (unsigned)n_seg),
                      dim3(256), 0, s, d_off.p, n_seg, seg_of.p);
-  hipLaunchKernelGGL(k_vox_insert, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, keys.p,
+  hipLaunchKernelGGL(k_vox_insert<T>, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, keys.p,
                      vals.p, cap - 1, status.p);
-  hipLaunchKernelGGL(k_vox_flag, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, keys.p, vals.p,
+  hipLaunchKernelGGL(k_vox_flag<T>, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, keys.p, vals.p,
                      cap - 1, flag.p);
   CS_LAUNCH_CHECK();
   size_t tmp_bytes = 0;
@@ -152,7 +166,7 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
   PoolBuf<char> tmp(tmp_bytes);
   CS_REQUIRE(tmp.p, CS_ERR_HIP, "cs_voxelize: scan scratch allocation failed");
   CS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, flag.p, pos.p, (int)n, s));
-  hipLaunchKernelGGL(k_vox_emit, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, flag.p, pos.p,
+  hipLaunchKernelGGL(k_vox_emit<T>, dim3(g), dim3(256), 0, s, d_xyz, seg_of.p, n, vs, flag.p, pos.p,
                      d_keep_idx, d_grid);
   hipLaunchKernelGGL(k_vox_offsets, dim3((unsigned)ceil_div(n_seg + 1, 256)), dim3(256), 0, s,
                      d_off.p, n_seg, n, pos.p, flag.p, d_out_off.p);
@@ -164,6 +178,24 @@ int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double 
   CS_REQUIRE(!h_status, CS_ERR_RANGE,
              "cs_voxelize: voxel index out of the supported range (|index| < 32768)");
   return CS_OK;
+}
+
+}  // namespace cs
+
+using namespace cs;
+
+extern "C" {
+
+int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
+                int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream) {
+  return voxelize_impl<float>(d_xyz, h_offsets, n_seg, voxel_size, d_keep_idx, d_grid, h_out_offsets,
+                              stream);
+}
+
+int cs_voxelize_f64(const double* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
+                    int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream) {
+  return voxelize_impl<double>(d_xyz, h_offsets, n_seg, voxel_size, d_keep_idx, d_grid, h_out_offsets,
+                               stream);
 }
 
 }  // extern "C"

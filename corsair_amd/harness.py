@@ -1,6 +1,6 @@
 """The build's counterpart of the hot part of the reference's evaluation.py:207-383:
 catalog / query feature extraction, descriptor retrieval, symmetry-aided registration and the metric
-aggregation, on the MI355X-native library.  Inputs are synthetic or arbitrary f32 clouds;
+aggregation, on the MI355X-native library.  Inputs are synthetic or arbitrary f32 / f64 clouds;
 dataset parsing, checkpoints-on-disk and the GUI of the reference are out of scope.
 
 Differences in structure (not in results) from the reference loops:
@@ -74,17 +74,46 @@ class Pipeline:
         return self.embed_batch_raw(xyz, offsets, self.cfg.voxel_size)
 
     def embed_batch_raw(self, xyz, offsets, voxel_size):
+        """xyz f32 or f64: quantised in its own type (backend.voxelize); the kept points of an f64 cloud
+        become f32 origins AFTER the selection (evaluation-shapenet.py:103-105; the collate of
+        datasets/ChairDataset.py:204-237 does the same to the f64 `rot_coords`)."""
         keep, grid, out_off = B.voxelize(xyz, offsets, voxel_size)
-        origin = xyz[keep]
+        origin = xyz[keep].to(torch.float32)
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=xyz.device)
         out, feat8, maps = self.engine.forward(grid, feats)
         desc = self.engine.embed(feat8, maps, len(offsets) - 1)
         return EmbeddedSet(out, origin, out_off, desc)
 
+    def embed_groups(self, groups, voxel_size=None):
+        """One forward over several groups of clouds that differ in type: groups = [(xyz, offsets), ...], each
+        quantised by its own cs_voxelize / cs_voxelize_f64 call, then collated into one batch (sample index =
+        position in the concatenation of the groups).  evaluation-shapenet.py:299-310 does this for a model
+        (f32, load_pc) and its posed copy (f64, generate_test_pc_pair) in every forward."""
+        vs = self.cfg.voxel_size if voxel_size is None else voxel_size
+        grids, origins, out_off, base = [], [], [0], 0
+        for xyz, offsets in groups:
+            keep, grid, off = B.voxelize(xyz, offsets, vs)
+            if base:
+                grid = grid.clone()
+                grid[:, 0] += base
+            grids.append(grid)
+            origins.append(xyz[keep].to(torch.float32))
+            out_off += [out_off[-1] + int(o) for o in off[1:]]
+            base += len(offsets) - 1
+        grid = torch.cat(grids)
+        feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=grid.device)
+        out, feat8, maps = self.engine.forward(grid, feats)
+        desc = self.engine.embed(feat8, maps, base)
+        return EmbeddedSet(out, torch.cat(origins), out_off, desc)
+
     def embed_clouds(self, clouds, batch_size=None):
-        """clouds: list of f32 [n,3] NumPy arrays (host).  Batches of batch_size like the reference's
-        DataLoader(bs=32)."""
+        """clouds: list of f32 or f64 [n,3] NumPy arrays (host), one type per call: a cloud is quantised in
+        the type it arrives in, so promoting or narrowing here would move points across voxel boundaries.
+        Batches of batch_size like the reference's DataLoader(bs=32)."""
         bs = batch_size or self.cfg.batch_size
+        kinds = {np.asarray(c).dtype for c in clouds}
+        if len(kinds) > 1 or not kinds <= {np.dtype(np.float32), np.dtype(np.float64)}:
+            raise TypeError("embed_clouds: clouds must all be float32 or all be float64, got %s" % sorted(map(str, kinds)))
         sets = []
         for i in range(0, len(clouds), bs):
             chunk = clouds[i:i + bs]
@@ -183,7 +212,8 @@ def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, cat
              register_top1=True, cache_dir=None, ignore_cache=False, force_gate=False, batch_size=None):
     """The reference's evaluation, end to end (evaluation.py:207-441), on the MI355X path.
 
-    catalog / queries: lists of f32 [n,3] clouds (already normalised) or EmbeddedSets; best_match int
+    catalog / queries: lists of [n,3] clouds (already normalised; f32 catalog clouds as CADLib loads them,
+    f64 posed queries as apply_transform leaves them -- each is quantised in its own type) or EmbeddedSets; best_match int
     [Q] (annotated CAD of every query), table f64 [C,C] pairwise Chamfer of the catalog (diag 0),
     base_T [Q,4,4] / lib_T [C,4,4] ground-truth poses (`base_T`, `pos_T` of the datasets), syms int [C].
       1. feature extraction of both sets in batches (evaluation.py:213-269),
@@ -270,7 +300,7 @@ class SyntheticScan2CAD:
             # (datasets/ScannetDataset.py:274); here: the CAD cloud itself under a seeded rotation,
             # re-sampled (other 10k of the 15k points) so voxel occupancy differs
             pc = synth.make_cloud(cids[cad], 15000)[15000 - self.n_points:]
-            self.queries.append(synth.apply_pose(pc, T))
+            self.queries.append(synth.apply_pose(pc, T, np.float64))   # apply_transform yields f64
             self.query_T.append(T)
             self.query_cad.append(cad)
         return self

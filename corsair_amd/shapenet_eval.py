@@ -35,10 +35,17 @@ class Config:
 
 
 def load_pc(pc):
-    """Centre and scale to unit radius (evaluation-shapenet.py:70-76); takes an array."""
-    pc = np.array(pc, dtype=np.float64)
-    pc -= pc.mean(axis=0, keepdims=True)
-    return pc / np.linalg.norm(pc, axis=1).max()
+    """Centre and scale to unit radius, IN PLACE in the array's own type like evaluation-shapenet.py:70-76
+    (`pc -= t; pc /= r` on what np.load returned: the ShapeNetPC15k files are f32, so everything up to the
+    pose product is f32 there); takes an array, works on a copy."""
+    pc = np.array(pc)
+    if pc.dtype not in (np.float32, np.float64):
+        pc = pc.astype(np.float64)
+    t = pc.mean(axis=0, keepdims=True)
+    pc -= t
+    r = np.linalg.norm(pc, axis=1).max()
+    pc /= r
+    return pc
 
 
 def generate_random_pose(cfg, rng):
@@ -112,15 +119,18 @@ def evaluate(pipe, clouds, cfg=None, pairs_per_batch=16, seed=None, force_gate=F
         label = get_symmetry_label(pc, cfg.symmetry_cd_threshold)
         for pi in range(cfg.n_poses_per_model):
             pose = generate_random_pose(cfg, rng)
-            jobs.append((mi, pi, pc.astype(np.float32), (pc @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32),
-                         pose, label))
+            # generate_test_pc_pair (:115-119): the model stays in its own type, the posed copy is the f64
+            # product with the f64 pose; quantize_pc (:97-107) floors each in its type and narrows afterwards
+            jobs.append((mi, pi, pc, pc @ pose[:3, :3].T + pose[:3, [3]].T, pose, label))
     results = []
     for s in range(0, len(jobs), pairs_per_batch):
         chunk = jobs[s:s + pairs_per_batch]
-        # one forward over [all models | all posed copies] of the chunk
-        xyz = torch.from_numpy(np.concatenate([j[2] for j in chunk] + [j[3] for j in chunk])).to(dev)
-        off = np.concatenate([[0], np.cumsum([len(j[2]) for j in chunk] + [len(j[3]) for j in chunk])]).tolist()
-        es = pipe.embed_batch_raw(xyz, off, cfg.voxel_size)
+        # one forward over [all models | all posed copies] of the chunk, every cloud quantised in its own type
+        groups = []
+        for col in (2, 3):
+            xyz = torch.from_numpy(np.concatenate([j[col] for j in chunk])).to(dev)
+            groups.append((xyz, np.concatenate([[0], np.cumsum([len(j[col]) for j in chunk])]).tolist()))
+        es = pipe.embed_groups(groups, cfg.voxel_size)
         P = len(chunk)
         base = es.gather(list(range(P)))
         posed = es.gather(list(range(P, 2 * P)))

@@ -86,8 +86,11 @@ def random_pose(pose_id, max_angle=np.pi, max_trans=1.0):
     return T
 
 
-def apply_pose(pc, T):
-    return (pc.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+def apply_pose(pc, T, dtype=np.float32):
+    """pc @ R.T + t in f64.  dtype=np.float64 keeps what the reference's apply_transform
+    (utils/preprocess.py:39-48) and generate_test_pc_pair (evaluation-shapenet.py:115-119) hand to the
+    quantiser: an f64 cloud, floored in f64, cast to f32 only after the selection."""
+    return (pc.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(dtype)
 
 
 # ---- weights -----------------------------------------------------------------------------------

@@ -143,12 +143,21 @@ int cs_instance_norm(int64_t n, int c, const float* d_in, int ld_in, const int32
  * Voxel quantisation.  Replaces ME.utils.sparse_quantize(floor(xyz/voxel), return_index=True,
  * return_maps_only=True) (utils/Info/CADLib.py:106-121, datasets/CategoryDataset.py:179-197):
  * for every cloud segment keep the first point of each voxel; kept indices ascending.
- * d_xyz f32 [n,3]; h_offsets int64 [n_seg+1] (host); d_keep_idx int64 [n] (capacity n, indices
+ * Grid index = floor(x / voxel) in the cloud's own type (NumPy: `f32 array / python float` divides in f32 —
+ * the catalog side, CADLib.py:106-121).  d_xyz f32 [n,3]; h_offsets int64 [n_seg+1] (host); d_keep_idx int64 [n] (capacity n, indices
  * into the concatenated cloud); d_grid int32 [n,4] (batch, x, y, z) of kept rows;
  * h_out_offsets int64 [n_seg+1] (host) receives the kept segment boundaries.
  * ---------------------------------------------------------------------------------------- */
 int cs_voxelize(const float* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
                 int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream);
+/* The same for f64 clouds, floor(x / voxel) in f64: what the QUERY side of the reference quantises —
+ * datasets/CategoryDataset.py:179-197 floors the f64 output of apply_transform (datasets/ScannetDataset.py:
+ * 278-282, utils/preprocess.py:39-48), evaluation-shapenet.py:97-119 floors `pc @ R.T + t` (f64) and casts
+ * the KEPT points to f32 afterwards (:103-105).  Narrowing such a cloud to f32 first moves a point across a
+ * voxel boundary on about 2 % of posed clouds; this entry does not narrow.  d_xyz f64 [n,3]; the rest as
+ * cs_voxelize.  The caller casts the kept origins to f32 after the selection, as the reference does. */
+int cs_voxelize_f64(const double* d_xyz, const int64_t* h_offsets, int n_seg, double voxel_size,
+                    int64_t* d_keep_idx, int32_t* d_grid, int64_t* h_out_offsets, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Descriptor retrieval.  Replaces scipy cdist + full argsort at utils/retrieval.py:139-177:

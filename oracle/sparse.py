@@ -43,10 +43,16 @@ def sparse_quantize(grid_coords):
 
 
 def quantize_cloud(xyz, voxel_size):
-    """CustomizeCADLib.quant (utils/Info/CADLib.py:106-121) on an f32 cloud: returns
-    (kept xyz, int32 grid coords [n,3], kept indices)."""
-    xyz = np.asarray(xyz, dtype=np.float32)
-    grid = np.floor(xyz / np.float32(voxel_size))
+    """`quant` of the reference (utils/Info/CADLib.py:106-121, datasets/CategoryDataset.py:179-197) and
+    `quantize_pc` (evaluation-shapenet.py:97-107): `np.floor(xyz / voxel_size)` in the cloud's OWN type
+    -- NumPy divides an f32 array by the Python float in f32 (the catalog clouds), an f64 array in f64
+    (posed queries: the output of apply_transform / `pc @ R.T + t`) -- first point of every voxel kept.
+    Returns (kept xyz in the input type, int32 grid coords [n,3], kept indices)."""
+    xyz = np.asarray(xyz)
+    if xyz.dtype not in (np.float32, np.float64):
+        raise TypeError("quantize_cloud: f32 or f64 clouds only, got %s" % xyz.dtype)
+    grid = np.floor(xyz / voxel_size)
+    assert grid.dtype == xyz.dtype
     keep = sparse_quantize(grid)
     return xyz[keep], grid[keep].astype(np.int32), keep
 

@@ -43,8 +43,11 @@ def _ref_symmetry_label(pc, thr):
 def test_get_symmetry_label(gpu, n_fold):
     from corsair_amd import shapenet_eval as S
 
-    pc = S.load_pc(_ring_cloud(n_fold, seed=n_fold))
-    want = _ref_symmetry_label(pc.astype(np.float32).astype(np.float64), 0.1)
+    # an f32 file like the ShapeNetPC15k clouds: load_pc normalises it in place in f32 (evaluation-shapenet.py:70-76),
+    # the reference's test then rotates with an f64 matrix and queries f64 KD-trees -- exactly _ref_symmetry_label(pc)
+    pc = S.load_pc(_ring_cloud(n_fold, seed=n_fold).astype(np.float32))
+    assert pc.dtype == np.float32
+    want = _ref_symmetry_label(pc, 0.1)
     got = S.get_symmetry_label(pc, 0.1)
     assert got == want
     if n_fold in (2, 3, 4, 6):
@@ -105,9 +108,10 @@ def test_shapenet_style_registration_eval(gpu):
     rng = np.random.default_rng(cfg.random_seed)
     pc = S.load_pc(clouds[0])
     pose = S.generate_random_pose(cfg, rng)
-    xyz = torch.from_numpy(np.concatenate([pc.astype(np.float32),
-                                           (pc @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32)])).to(gpu)
-    es = pipe.embed_batch_raw(xyz, [0, len(pc), 2 * len(pc)], cfg.voxel_size)
+    assert pc.dtype == np.float32                       # synth clouds are f32 like the ShapeNetPC15k files
+    posed = pc @ pose[:3, :3].T + pose[:3, [3]].T       # f64, quantised in f64 (evaluation-shapenet.py:97-119)
+    es = pipe.embed_groups([(torch.from_numpy(pc).to(gpu), [0, len(pc)]),
+                            (torch.from_numpy(posed).to(gpu), [0, len(posed)])], cfg.voxel_size)
     o = es.offsets
     F, X = es.F.cpu().numpy(), es.origin.cpu().numpy()
     a0 = R.draw_anchors(o[1], 100, 0)

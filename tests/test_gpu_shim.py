@@ -164,6 +164,73 @@ def test_gpu_voxelize_matches_sparse_quantize(gpu):
         assert out_off == np.concatenate([[0], np.cumsum([len(g) for g in grids])]).tolist()
 
 
+def test_gpu_voxelize_f64_floors_what_the_reference_floors(gpu):
+    """the QUERY side of the reference quantises f64 clouds -- datasets/CategoryDataset.py:179-197 floors
+    the f64 output of apply_transform, evaluation-shapenet.py:97-119 floors `pc @ R.T + t` and narrows the KEPT points
+    afterwards.  cs_voxelize_f64 on 200 f64-posed clouds: kept indices and grids equal np.floor(p64 / voxel) + first
+    occurrence exactly (plain NumPy here, not the oracle), and the set contains clouds on which narrowing to f32 first
+    (what the f32 entry would see) puts a point into another voxel."""
+    from corsair_amd import backend as B, synth
+    from oracle import sparse
+
+    voxel = 0.03
+    clouds = [synth.apply_pose(synth.make_cloud(c, 15000)[:10000], synth.random_pose(c), np.float64) for c in range(200)]
+    assert all(c.dtype == np.float64 for c in clouds)
+    moved, other_keep = 0, 0
+    for s in range(0, 200, 40):
+        chunk = clouds[s:s + 40]
+        off = np.concatenate([[0], np.cumsum([len(c) for c in chunk])]).tolist()
+        xyz = torch.from_numpy(np.concatenate(chunk)).to(gpu)
+        assert xyz.dtype == torch.float64
+        keep, grid, out_off = B.voxelize(xyz, off, voxel)
+        keep, grid = keep.cpu().numpy(), grid.cpu().numpy()
+        k32, g32, _ = (t.cpu().numpy() if torch.is_tensor(t) else t for t in B.voxelize(xyz.to(torch.float32), off, voxel))
+        for b, c in enumerate(chunk):
+            g = np.floor(c / voxel)                                    # the reference's expression, f64
+            _, first = np.unique(g.astype(np.int64), axis=0, return_index=True)
+            first = np.sort(first)
+            lo, hi = out_off[b], out_off[b + 1]
+            assert np.array_equal(keep[lo:hi] - off[b], first), (s + b)
+            assert np.array_equal(grid[lo:hi, 1:], g[first].astype(np.int32)) and (grid[lo:hi, 0] == b).all()
+            # the oracle restates the same thing, type-preserving
+            _, og, ok = sparse.quantize_cloud(c, voxel)
+            assert np.array_equal(ok, first) and np.array_equal(og, grid[lo:hi, 1:])
+            g_narrow = np.floor(c.astype(np.float32) / np.float32(voxel))
+            if not np.array_equal(g_narrow.astype(np.float64), g):
+                moved += 1
+                sel = (k32 >= off[b]) & (k32 < off[b + 1])
+                if not (np.array_equal(k32[sel] - off[b], first) and np.array_equal(g32[sel][:, 1:], g[first].astype(np.int32))):
+                    other_keep += 1
+    assert moved >= 3 and other_keep >= 1, (moved, other_keep)
+
+
+def test_embed_groups_quantises_every_cloud_in_its_own_type(gpu):
+    """Pipeline.embed_groups = evaluation-shapenet.py:299-310: an f32 model and its f64 posed copy in one forward; the
+    result equals two separate embeds (eval-mode BN: samples are independent), origins are the kept points narrowed
+    AFTER the selection."""
+    from corsair_amd import harness, synth
+
+    sd, emb = synth.make_state_dicts(31)
+    pipe = harness.Pipeline(sd, emb, device=gpu)
+    pc = synth.make_cloud(110, 15000)[:10000]
+    posed = synth.apply_pose(pc, synth.random_pose(110), np.float64)
+    a = torch.from_numpy(pc).to(gpu)
+    b = torch.from_numpy(posed).to(gpu)
+    both = pipe.embed_groups([(a, [0, len(pc)]), (b, [0, len(posed)])])
+    ea = pipe.embed_batch(a, [0, len(pc)])
+    eb = pipe.embed_batch(b, [0, len(posed)])
+    o = both.offsets
+    assert o == [0, ea.offsets[1], ea.offsets[1] + eb.offsets[1]]
+    assert torch.equal(both.F[:o[1]], ea.F) and torch.equal(both.F[o[1]:], eb.F)
+    assert torch.equal(both.origin[o[1]:], eb.origin) and both.origin.dtype == torch.float32
+    assert torch.equal(both.desc, torch.cat([ea.desc, eb.desc]))
+    g = np.floor(posed / 0.03)
+    _, first = np.unique(g.astype(np.int64), axis=0, return_index=True)
+    assert np.array_equal(eb.origin.cpu().numpy(), posed[np.sort(first)].astype(np.float32))
+    with pytest.raises(TypeError):
+        pipe.embed_clouds([pc, posed])
+
+
 def test_fused_bn_epilogue_matches_torch_batchnorm1d(gpu):
     """MinkowskiBatchNorm is nn.BatchNorm1d over the rows (model/common.py:22).  The product folds it into the
     convolution epilogue; here the un-normalised GPU convolution goes through the torch module itself (eval

@@ -132,6 +132,33 @@ def test_sparse_quantize_keeps_first_point_per_voxel():
     assert c.dtype == np.int32 and c.shape == (len(grid) + 10, 4) and (c[-10:, 0] == 1).all()
 
 
+def test_quantize_cloud_floors_in_the_clouds_own_type():
+    """The reference floors `rot_coords / voxel_size` in whatever type the cloud has: f32 for the catalog
+    (utils/Info/CADLib.py:106-121), f64 for posed queries (datasets/CategoryDataset.py:179-197 on apply_transform's
+    output, evaluation-shapenet.py:97-119).  The oracle preserves the type; narrowing first changes voxels."""
+    from corsair_amd import synth
+    from oracle import sparse
+
+    moved = 0
+    for c in (63, 110, 186, 197, 5):
+        p64 = synth.apply_pose(synth.make_cloud(c, 15000)[:10000], synth.random_pose(c), np.float64)
+        xyz, grid, keep = sparse.quantize_cloud(p64, 0.03)
+        assert xyz.dtype == np.float64
+        g = np.floor(p64 / 0.03)
+        seen = {}
+        for i, v in enumerate(map(tuple, g.astype(np.int64))):
+            seen.setdefault(v, i)
+        assert sorted(seen.values()) == keep.tolist() and np.array_equal(grid, g[keep].astype(np.int32))
+        p32 = p64.astype(np.float32)
+        x32, g32, k32 = sparse.quantize_cloud(p32, 0.03)
+        assert x32.dtype == np.float32
+        assert np.array_equal(g32, np.floor(p32 / np.float32(0.03))[k32].astype(np.int32))
+        moved += int(not np.array_equal(np.floor(p32 / np.float32(0.03)).astype(np.float64), g))
+    assert moved >= 3
+    with pytest.raises(TypeError):
+        sparse.quantize_cloud(np.zeros((4, 3), np.int32), 0.03)
+
+
 def test_strided_map_first_occurrence_order_and_kernel_map_properties():
     from oracle import sparse
 
