@@ -84,6 +84,8 @@ def parse():
                     help="query batches in flight in the timed region (host threads x HIP streams)")
     ap.add_argument("--no-solo-probe", action="store_true",
                     help="skip the extra pass that times the dominant kernel without concurrent work")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="chair, 1 GPU: skip the short table (configs[2]) and stress (configs[4]) legs reported as `workloads`")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra pass with three batches in flight reported as `batches_in_flight`")
     return ap.parse_args()
@@ -691,6 +693,118 @@ def roofline_by_kernel(fam, args):
     return out
 
 
+class Runner:
+    """Runs steps [first, last) of a workload with `depth` batches in flight.  Worker threads are PERSISTENT (one
+    single-thread executor each): the library caches scratch per host thread and the helper thread / streams of a
+    worker are created on its first step, so a worker that is started for the timed pass only would pay hipMalloc
+    and thread start-up inside the timed region."""
+
+    def __init__(self, ctx, wl, depth):
+        import torch
+
+        self.ctx, self.wl, self.depth = ctx, wl, depth
+        self.streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 3))]
+        self.workers = {}
+
+    def worker_of(self, w):
+        from concurrent.futures import ThreadPoolExecutor
+
+        if w not in self.workers:
+            self.workers[w] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="bench-worker%d" % w)
+        return self.workers[w]
+
+    def run_steps(self, first, last, depth=None):
+        import torch
+
+        depth = self.depth if depth is None else depth
+        wl, ctx, streams = self.wl, self.ctx, self.streams
+        if depth == 1:
+            for b in range(first, last):
+                wl.step(b)
+            return
+
+        def work(w):
+            torch.cuda.set_device(ctx.dev_index)
+            with torch.cuda.stream(streams[w]):
+                for b in range(first + w, last, depth):
+                    wl.step(b)
+                streams[w].synchronize()
+
+        futures = [self.worker_of(w).submit(work, w) for w in range(depth)]
+        for f in futures:
+            f.result()              # surfaces worker failures in the main thread
+
+    def close(self):
+        for ex in self.workers.values():
+            ex.shutdown(wait=True)
+        self.workers.clear()
+
+
+def timed_region(ctx, wl, runner, warmup, steps):
+    """The contract's measurement: W untimed warmup steps, then EXACTLY K steps bracketed by barrier +
+    torch.cuda.synchronize() on both sides, the library's HIP-event profile (events on the launch streams) switched on
+    for exactly those steps.  Returns (barrier-to-barrier seconds, this rank's own seconds, per-family profile)."""
+    import torch
+
+    from corsair_amd import _lib
+
+    runner.run_steps(0, warmup)
+    ctx.log("warmup done")
+    wl.results.clear()
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    ctx.barrier()
+    t_start = time.time()
+    runner.run_steps(warmup, warmup + steps)
+    torch.cuda.synchronize()
+    own_elapsed = time.time() - t_start
+    ctx.barrier()
+    elapsed = time.time() - t_start
+    _lib.prof_enable(False)
+    ctx.log("timed region: %d steps in %.3fs" % (steps, elapsed))
+    fam = {}
+    for name in FAMILIES:
+        ms, n, units = _lib.prof_get(name)
+        fam[name] = {"ms": ms, "launches": n, "flop": units}
+    return elapsed, own_elapsed, fam
+
+
+LEG_STEPS, LEG_WARMUP = 8, 2
+
+
+def extra_workload_leg(ctx, args, name):
+    """One short leg of another BASELINE.json config inside the default run (configs[2] and configs[4]
+    under the driver's clock): the same timed_region as the headline (2 warmup + 8 timed steps, sequential), on its own
+    workload object, reported under `workloads[name]` with the same arithmetic (value = units / elapsed)."""
+    import copy
+
+    import torch
+
+    leg_args = argparse.Namespace(**vars(args))
+    leg_args.workload, leg_args.steps, leg_args.warmup, leg_args.catalog, leg_args.pipeline = name, LEG_STEPS, LEG_WARMUP, 0, 1
+    lctx = copy.copy(ctx)
+    lctx.args = leg_args
+    t0 = time.time()
+    wl = StressWorkload(lctx) if name == "stress" else RegistrationWorkload(lctx, name)
+    wl.setup()
+    runner = Runner(lctx, wl, 1)
+    elapsed, _, fam = timed_region(lctx, wl, runner, LEG_WARMUP, LEG_STEPS)
+    runner.close()
+    cfg = wl.config(LEG_STEPS)
+    units = LEG_STEPS * wl.units_per_step
+    leg = {"value": units / elapsed, "unit": "queries/s", "steps": LEG_STEPS, "warmup": LEG_WARMUP,
+           "ms_per_step": elapsed / LEG_STEPS * 1e3, "units_per_step": wl.units_per_step,
+           "config": cfg, "roofline": roofline_of(fam, None, leg_args),
+           "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()}}
+    if name == "stress":
+        leg["kernel_tflops"] = {k: round(fam[k]["flop"] / max(fam[k]["ms"], 1e-9) / 1e9, 2) for k in ("conv", "topk")}
+        leg["est_full_job_s"] = 100000.0 / leg["value"]
+    del wl, runner
+    torch.cuda.empty_cache()
+    leg["leg_wall_s"] = round(time.time() - t0, 2)
+    return leg
+
+
 def main():
     args = parse()
     maybe_self_launch(args)
@@ -710,54 +824,9 @@ def main():
         sys.stderr.write("[bench] --pipeline %d with %d ranks: this workload's step contains a collective, batches in flight "
                          "would interleave the ranks' collectives; refusing\n" % (depth, ctx.world))
         sys.exit(2)
-    streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 3))]
-
-    # worker threads are PERSISTENT (one single-thread executor each): the library caches scratch per host
-    # thread and the helper thread / streams of a worker are created on its first step, so a worker that is
-    # started for the timed pass only would pay hipMalloc and thread start-up inside the timed region
-    from concurrent.futures import ThreadPoolExecutor
-    workers = {}
-
-    def worker_of(w):
-        if w not in workers:
-            workers[w] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="bench-worker%d" % w)
-        return workers[w]
-
-    def run_steps(first, last, depth=depth):
-        if depth == 1:
-            for b in range(first, last):
-                wl.step(b)
-            return
-
-        def work(w):
-            torch.cuda.set_device(ctx.dev_index)
-            with torch.cuda.stream(streams[w]):
-                for b in range(first + w, last, depth):
-                    wl.step(b)
-                streams[w].synchronize()
-
-        futures = [worker_of(w).submit(work, w) for w in range(depth)]
-        for f in futures:
-            f.result()              # surfaces worker failures in the main thread
-
-    run_steps(0, args.warmup)
-    ctx.log("warmup done")
-    wl.results.clear()
-    _lib.prof_enable(True)
-    _lib.prof_reset()
-    ctx.barrier()
-    t_start = time.time()
-    run_steps(args.warmup, args.warmup + args.steps)
-    torch.cuda.synchronize()
-    own_elapsed = time.time() - t_start
-    ctx.barrier()
-    elapsed = time.time() - t_start
-    _lib.prof_enable(False)
-    ctx.log("timed region: %d steps in %.3fs" % (args.steps, elapsed))
-    fam = {}
-    for name in FAMILIES:
-        ms, n, units = _lib.prof_get(name)
-        fam[name] = {"ms": ms, "launches": n, "flop": units}
+    runner = Runner(ctx, wl, depth)
+    run_steps = runner.run_steps
+    elapsed, own_elapsed, fam = timed_region(ctx, wl, runner, args.warmup, args.steps)
     # In the timed region the prefilter launches of a step overlap other work (the vanilla and the
     # symmetric RANSAC calls run on two host threads, the small kernels of a round run under the next
     # prefilter), so their event-bracketed durations include the share of the GPU they did not have.
@@ -855,6 +924,9 @@ def main():
                         "neighbours' kernels)"}
         if ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
+        if ctx.world == 1 and args.workload == "chair" and not args.no_extra_workloads:
+            # configs[2] and configs[4] under the same clock as the headline (short legs, same measurement)
+            out["workloads"] = {name: extra_workload_leg(ctx, args, name) for name in ("table", "stress")}
         print(json.dumps(out))
     if ctx.dist is not None:
         ctx.dist.barrier()

@@ -156,6 +156,89 @@ __device__ __forceinline__ void jacobi4(double a[4][4], double v[4][4]) {
   }
 }
 
+// Largest eigenpair of the Horn matrix from its characteristic polynomial (round 4; oracle/corsair_oracle.c
+// oc_horn_qcp is the same operation sequence, so the hypotheses stay bit-identical).  N is symmetric and
+// traceless: P(l) = l^4 + c2 l^2 + c1 l + c0, c2 = -2 |S|_F^2, c1 = -8 det S, c0 = det N.  All roots are real,
+// so Halley's iteration from the upper bound sqrt(3) |S|_F descends monotonically onto the largest one with
+// cubic order (3-6 steps, one f64 divide each); the eigenvector is the row of adj(N - l I) with the largest
+// diagonal entry.  Against the 5-sweep Jacobi (30 rotations x 2 IEEE sqrt + 2 IEEE divides, ~3 000 f64
+// instructions) this is ~400.  Accepted only when the iteration converged and P'(l) >= 0.02 l^3 (the largest
+// eigenvalue is well separated); the caller falls back to jacobi4 otherwise (3 in 10^5 samples on the bench).
+__device__ __forceinline__ bool horn_qcp(const double (&S)[3][3], const double (&N)[4][4], double (&q)[4]) {
+  double f2 = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) f2 = fma(S[a][b], S[a][b], f2);
+  const double c2 = -2.0 * f2;
+  const double detS = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) -
+                      S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+                      S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+  const double c1 = -8.0 * detS;
+  const double u5 = N[0][2] * N[1][3] - N[0][3] * N[1][2];
+  const double w0 = N[2][0] * N[3][1] - N[2][1] * N[3][0];
+  double c0;
+  {
+    const double u0 = N[0][0] * N[1][1] - N[0][1] * N[1][0];
+    const double u1 = N[0][0] * N[1][2] - N[0][2] * N[1][0];
+    const double u2 = N[0][0] * N[1][3] - N[0][3] * N[1][0];
+    const double u3 = N[0][1] * N[1][2] - N[0][2] * N[1][1];
+    const double u4 = N[0][1] * N[1][3] - N[0][3] * N[1][1];
+    const double w1 = N[2][0] * N[3][2] - N[2][2] * N[3][0];
+    const double w2 = N[2][0] * N[3][3] - N[2][3] * N[3][0];
+    const double w3 = N[2][1] * N[3][2] - N[2][2] * N[3][1];
+    const double w4 = N[2][1] * N[3][3] - N[2][3] * N[3][1];
+    const double w5 = N[2][2] * N[3][3] - N[2][3] * N[3][2];
+    c0 = u0 * w5 - u1 * w4 + u2 * w3 + u3 * w2 - u4 * w1 + u5 * w0;
+  }
+  double lam = sqrt(3.0 * f2);
+  bool conv = false;
+  for (int it = 0; it < 8 && !conv; ++it) {
+    const double l2 = lam * lam;
+    const double P = fma(fma(l2 + c2, lam, c1), lam, c0);
+    const double dP = fma(fma(4.0, l2, 2.0 * c2), lam, c1);
+    const double ddP = fma(12.0, l2, 2.0 * c2);
+    const double d = (2.0 * P * dP) / fma(2.0 * dP, dP, -(P * ddP));
+    lam = lam - d;
+    conv = fabs(d) <= 1e-6 * lam;  // false for NaN
+  }
+  {
+    const double l2 = lam * lam;
+    const double dP = fma(fma(4.0, l2, 2.0 * c2), lam, c1);
+    if (!(conv && dP >= 0.02 * (l2 * lam))) return false;
+  }
+  const double m00 = N[0][0] - lam, m11 = N[1][1] - lam, m22 = N[2][2] - lam, m33 = N[3][3] - lam;
+  const double m01 = N[0][1], m02 = N[0][2], m03 = N[0][3], m12 = N[1][2], m13 = N[1][3], m23 = N[2][3];
+  const double u0 = m00 * m11 - m01 * m01;
+  const double u1 = m00 * m12 - m02 * m01;
+  const double u2 = m00 * m13 - m03 * m01;
+  const double u3 = m01 * m12 - m02 * m11;
+  const double u4 = m01 * m13 - m03 * m11;
+  const double w1 = m02 * m23 - m22 * m03;
+  const double w2 = m02 * m33 - m23 * m03;
+  const double w3 = m12 * m23 - m22 * m13;
+  const double w4 = m12 * m33 - m23 * m13;
+  const double w5 = m22 * m33 - m23 * m23;
+  const double a00 = m11 * w5 - m12 * w4 + m13 * w3;
+  const double a01 = -m01 * w5 + m02 * w4 - m03 * w3;
+  const double a02 = m13 * u5 - m23 * u4 + m33 * u3;
+  const double a03 = -m12 * u5 + m22 * u4 - m23 * u3;
+  const double a11 = m00 * w5 - m02 * w2 + m03 * w1;
+  const double a12 = -m03 * u5 + m23 * u2 - m33 * u1;
+  const double a13 = m02 * u5 - m22 * u2 + m23 * u1;
+  const double a22 = m03 * u4 - m13 * u2 + m33 * u0;
+  const double a23 = -m02 * u4 + m12 * u2 - m23 * u0;
+  const double a33 = m02 * u3 - m12 * u1 + m22 * u0;
+  (void)w0;
+  // row of the largest |diagonal| (first one on ties), selected without dynamic indexing
+  double best = fabs(a00);
+  q[0] = a00; q[1] = a01; q[2] = a02; q[3] = a03;
+  if (fabs(a11) > best) { best = fabs(a11); q[0] = a01; q[1] = a11; q[2] = a12; q[3] = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); q[0] = a02; q[1] = a12; q[2] = a22; q[3] = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); q[0] = a03; q[1] = a13; q[2] = a23; q[3] = a33; }
+  return best > 0.0;
+}
+
 // hyp layout: [prob][12][bmax] (structure of arrays), element 4a+b = R[a][b], 4a+3 = t[a]
 // RN = ransac_n when it is known at compile time (10: the reference's value; the sampled pairs then stay
 // in registers between the centroid and the covariance pass), 0 = read it from the argument
@@ -176,7 +259,8 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     int bcount, int bmax, int ransac_n,
                                                     uint64_t seed,
                                                     const int32_t* __restrict__ xcd_prob, const XcdTab xcd_tab,
-                                                    int slots, int tiles, double* __restrict__ hyp) {
+                                                    int slots, int tiles, int force_jacobi,
+                                                    double* __restrict__ hyp) {
   // 1-D grid dealt round-robin to the XCDs: XCD x samples only the problems xcd_prob[x][.], whose
   // correspondences then stay in that XCD's L2 (the sampling is a random gather of 24-B rows)
   const int xcd = blockIdx.x & 7;
@@ -268,20 +352,25 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
   N[2][1] = N[1][2];
   N[3][1] = N[1][3];
   N[3][2] = N[2][3];
-  jacobi4(N, V);
-  // eigenvector of the largest eigenvalue (ties -> lowest index), selected without dynamic indexing
-  double best = N[0][0];
-  double qw = V[0][0], qx = V[1][0], qy = V[2][0], qz = V[3][0];
+  double qv[4];
+  if (force_jacobi || !horn_qcp(S, N, qv)) {
+    // rare (ill-separated largest eigenvalue): the lanes that need it run the Jacobi solver
+    jacobi4(N, V);
+    // eigenvector of the largest eigenvalue (ties -> lowest index), selected without dynamic indexing
+    double best = N[0][0];
+    qv[0] = V[0][0]; qv[1] = V[1][0]; qv[2] = V[2][0]; qv[3] = V[3][0];
 #pragma unroll
-  for (int c = 1; c < 4; ++c) {
-    if (N[c][c] > best) {
-      best = N[c][c];
-      qw = V[0][c];
-      qx = V[1][c];
-      qy = V[2][c];
-      qz = V[3][c];
+    for (int c = 1; c < 4; ++c) {
+      if (N[c][c] > best) {
+        best = N[c][c];
+        qv[0] = V[0][c];
+        qv[1] = V[1][c];
+        qv[2] = V[2][c];
+        qv[3] = V[3][c];
+      }
     }
   }
+  double qw = qv[0], qx = qv[1], qy = qv[2], qz = qv[3];
   const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
   qw = qw / qn;
   qx = qx / qn;
@@ -1329,6 +1418,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // GPU while the back half of round i (many small dependent kernels) and the host turnaround run.
   // Its skip tests read est_k / done while they may be updated (prob_view); its placement table is
   // built from the state one round earlier: finished problems cost a few empty workgroups.
+  // CS_RANSAC_JACOBI=1: every hypothesis through the Jacobi eigen-solver (the fallback of horn_qcp; the oracle's
+  // oc_rigid_fit_force_jacobi is its counterpart) -- tests and A/B timing
+  const int force_jacobi = getenv("CS_RANSAC_JACOBI") && atoi(getenv("CS_RANSAC_JACOBI")) != 0;
   const char* env_ov = getenv("CS_RANSAC_OVERLAP");
   hipStream_t side = (env_ov && env_ov[0] == '0') ? nullptr : side_stream();
   // ... and the hypotheses of a side-stream front half go to a THIRD stream: those of round i+2 are enqueued when round i
@@ -1398,10 +1490,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       const int htiles = (b + 255) / 256;
       if (ransac_n == 10)
         hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r);
       else
         hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r);
     }
     if (f.pf) {
       _Float16* A16_r = A16.p + (size_t)par * n_prob * bmax * PF_K;

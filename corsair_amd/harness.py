@@ -122,6 +122,17 @@ class Pipeline:
             sets.append(self.embed_batch(xyz, off))
         return concat_sets(sets)
 
+    def voxel_counts(self, clouds, chunk=64):
+        """Voxels each cloud quantises to (cs_voxelize / cs_voxelize_f64 only): the weight multi-GPU runs balance their
+        shards by (N1 varies 1.6 k - 8 k per model)."""
+        counts = []
+        for i in range(0, len(clouds), chunk):
+            part = [np.asarray(c) for c in clouds[i:i + chunk]]
+            off = np.concatenate([[0], np.cumsum([len(c) for c in part])]).tolist()
+            _, _, out_off = B.voxelize(torch.from_numpy(np.concatenate(part, 0)).to(self.device), off, self.cfg.voxel_size)
+            counts += [int(v) for v in np.diff(out_off)]
+        return counts
+
     # ---- retrieval (evaluation.py:272-283) ----------------------------------------------------------
     def retrieve(self, q_desc, lib_desc, k):
         return B.l2_topk(q_desc, lib_desc, k)
@@ -224,42 +235,72 @@ def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, cat
       4. aggregation + the log block (evaluation.py:334-383), 5. the result cache (evaluation.py:421-441).
     Returns an EvalResult."""
     from . import cache as C_
-    from .utils import retrieval
 
     cfg = pipe.cfg
     bs = batch_size or cfg.batch_size
     cat = catalog if isinstance(catalog, EmbeddedSet) else pipe.embed_clouds(catalog, bs)
     qs = queries if isinstance(queries, EmbeddedSet) else pipe.embed_clouds(queries, bs)
-    Q, C = len(qs), len(cat)
+    Q = len(qs)
     best_match = np.asarray(best_match).astype(np.int64)
     syms = np.asarray(syms)
-    stat = retrieval.scan2cad_retrieval_eval(qs.desc, cat.desc, best_match, table, int(0.1 * np.asarray(table).shape[1]))
+    stat = retrieval_stat(pipe, qs.desc, cat.desc, best_match, table)
 
     per_query = None if (ignore_cache or cache_dir is None) else C_.load_results(cache_dir, category, register_top1)
     from_cache = per_query is not None
     if per_query is None:
         pos_idx = np.asarray(stat["top1_predict" if register_top1 else "gt"], dtype=np.int64)
-        out = {k: [] for k in C_.NAMES}
-        for s in range(0, Q, bs):
-            ids = np.arange(s, min(Q, s + bs))
-            q = qs.gather(ids)
-            cads = cat.gather(pos_idx[ids])
-            cad_sym = syms[pos_idx[ids]]
-            res = pipe.register(q, cads, cad_sym, anchor_ids=[(2 * int(i), 2 * int(i) + 1) for i in ids],
-                                force_gate=force_gate)
-            Tr, Tb, cdr, cdb = (t.cpu().numpy() for t in (res.T_ransac, res.T_best, res.cd_ransac, res.cd_best))
-            T0 = [base_T[i] for i in ids]
-            T1 = [lib_T[j] for j in pos_idx[ids]]
-            t_r, r_r = pose_losses(Tr, T0, T1, cad_sym)
-            t_s, r_s = pose_losses(Tb, T0, T1, cad_sym)
-            for k, v in (("Ts_est_ransac", Tr), ("Ts_est_best", Tb), ("t_losses_ransac", t_r),
-                         ("t_losses_sym", t_s), ("r_losses_ransac", r_r), ("r_losses_sym", r_s),
-                         ("sym_ransac_success", res.ok), ("chamfer_dist_ransac", cdr), ("chamfer_dist_sym", cdb)):
-                out[k].append(np.asarray(v))
-        per_query = {k: np.concatenate(v) for k, v in out.items()}
+        per_query = register_queries(pipe, qs, np.arange(Q), cat, pos_idx, syms, base_T, lib_T, force_gate, bs)
         if cache_dir is not None:
             C_.save_results(cache_dir, category, register_top1, per_query)
+    return finish_eval(stat, per_query, from_cache)
 
+
+def retrieval_stat(pipe, q_desc, lib_desc, best_match, table):
+    """scan2cad_retrieval_eval with Precision@M, M = int(0.1 C) (evaluation.py:272-283): the ranking comes from
+    pipe.retrieve (cs_l2_topk), the statistics from utils.retrieval."""
+    from .utils import retrieval
+
+    pos_n = int(0.1 * np.asarray(table).shape[1])
+    rank = pipe.retrieve(q_desc, lib_desc, max(pos_n, 1))
+    rank = rank.cpu().numpy() if torch.is_tensor(rank) else np.asarray(rank)
+    return retrieval.scan2cad_retrieval_eval_rank(rank, table, best_match, pos_n)
+
+
+def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, force_gate=False, batch_size=None):
+    """The registration loop of evaluation.py:297-331 over the embedded queries `qs`, whose GLOBAL query numbers are
+    `query_ids` (they seed the anchor draws, so a query gives the same result whichever rank or batch it lands in):
+    sym_pose against CAD pos_idx[q] and eval_pose of both estimates, batched.  Returns the nine arrays of
+    evaluation.py:421-441 (cache.NAMES) for these queries, in the order of `query_ids`."""
+    from . import cache as C_
+
+    bs = batch_size or pipe.cfg.batch_size
+    query_ids = np.asarray(query_ids, dtype=np.int64)
+    out = {k: [] for k in C_.NAMES}
+    for s in range(0, len(query_ids), bs):
+        loc = np.arange(s, min(len(query_ids), s + bs))
+        ids = query_ids[loc]
+        q = qs.gather(loc)
+        cads = cat.gather(pos_idx[ids])
+        cad_sym = syms[pos_idx[ids]]
+        res = pipe.register(q, cads, cad_sym, anchor_ids=[(2 * int(i), 2 * int(i) + 1) for i in ids],
+                            force_gate=force_gate)
+        Tr, Tb, cdr, cdb = (t.cpu().numpy() for t in (res.T_ransac, res.T_best, res.cd_ransac, res.cd_best))
+        T0 = [base_T[i] for i in ids]
+        T1 = [lib_T[j] for j in pos_idx[ids]]
+        t_r, r_r = pose_losses(Tr, T0, T1, cad_sym)
+        t_s, r_s = pose_losses(Tb, T0, T1, cad_sym)
+        for k, v in (("Ts_est_ransac", Tr), ("Ts_est_best", Tb), ("t_losses_ransac", t_r),
+                     ("t_losses_sym", t_s), ("r_losses_ransac", r_r), ("r_losses_sym", r_s),
+                     ("sym_ransac_success", res.ok), ("chamfer_dist_ransac", cdr), ("chamfer_dist_sym", cdb)):
+            out[k].append(np.asarray(v))
+    if not len(query_ids):
+        return {k: np.zeros((0, 4, 4), np.float32) if k.startswith("Ts_est") else
+                np.zeros(0, bool if k == "sym_ransac_success" else np.float64) for k in C_.NAMES}
+    return {k: np.concatenate(v) for k, v in out.items()}
+
+
+def finish_eval(stat, per_query, from_cache):
+    """Aggregation + the log block (evaluation.py:334-383) over the per-query arrays of ALL queries."""
     ransac = aggregate(per_query["r_losses_ransac"], per_query["t_losses_ransac"], per_query["chamfer_dist_ransac"])
     sym = aggregate(per_query["r_losses_sym"], per_query["t_losses_sym"], per_query["chamfer_dist_sym"])
     for a, r in ((ransac, per_query["r_losses_ransac"]), (sym, per_query["r_losses_sym"])):

@@ -176,3 +176,80 @@ def catalog_shard(n_items, rank, world):
     """Contiguous row range [first, last) of the descriptor catalog owned by `rank`."""
     per = (n_items + world - 1) // world
     return min(rank * per, n_items), min((rank + 1) * per, n_items)
+
+
+# ---- the whole evaluation on N ranks, ending in ONE result set (evaluation.py:207-441) ------------------------------
+def voxel_balanced_shards(dist, pipe, clouds, rank, world):
+    """Shards of a list of clouds balanced by VOXEL count: every rank quantises an interleaved slice
+    (`pipe.voxel_counts`: cs_voxelize only), the counts are all-gathered, balanced_shards deals the items out.
+    Identical on every rank."""
+    n = len(clouds)
+    mine = shard_ids(n, rank, world)
+    counts = pipe.voxel_counts([clouds[c] for c in mine]) if mine else []
+    return balanced_shards(all_gather_counts(dist, mine, counts, n, world), world)
+
+
+def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, table, base_T, lib_T, syms, category="chair",
+                     register_top1=True, cache_dir=None, force_gate=False, batch_size=None):
+    """harness.run_eval on `world` ranks (one process per GPU), strong scaling: ONE evaluation of all Q queries.
+
+      1. catalog clouds dealt to the ranks by voxel count, embedded, ONE all-gather of the embedded catalog
+         (descriptors + voxel features + origins: any rank can register against whichever CAD retrieval selects);
+      2. query clouds dealt to the ranks by voxel count and embedded; their descriptors (Q x 256 f32, 1 MB for the
+         chair set) are all-gathered so that every rank holds the retrieval statistics of evaluation.py:272-283;
+      3. every rank registers ITS queries against their top-1 (or annotated) CAD -- no collective;
+      4. the per-query outputs (the nine arrays of evaluation.py:421-441) are all-gathered and put back into query
+         order; rank 0 aggregates, prints and writes the result cache once (evaluation.py:334-383,421-441).
+    Anchor draws are seeded by the GLOBAL query number and every kernel on the path computes a sample independently of
+    its batch neighbours, so the result equals the single-rank run_eval bit for bit (tests/test_sharding_gloo.py,
+    tests/test_gpu_next_rows.py).  Returns the EvalResult on every rank (`report` is printed by the caller)."""
+    from . import cache as C_
+    from . import harness as H
+
+    if dist is None or world == 1:
+        return H.run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, category, register_top1,
+                          cache_dir, True, force_gate, batch_size)
+    cfg = pipe.cfg
+    bs = batch_size or cfg.batch_size
+    dev = pipe.device
+    C, Q = len(catalog), len(queries)
+    best_match = np.asarray(best_match).astype(np.int64)
+    syms = np.asarray(syms)
+    # 1. catalog
+    cshards = voxel_balanced_shards(dist, pipe, catalog, rank, world)
+    cat_local = pipe.embed_clouds([catalog[c] for c in cshards[rank]], bs) if cshards[rank] else _empty_set(dev)
+    cat = gather_catalog(dist, cat_local, C, world, cshards)
+    # 2. queries
+    qshards = voxel_balanced_shards(dist, pipe, queries, rank, world)
+    mine = np.asarray(qshards[rank], dtype=np.int64)
+    qs = pipe.embed_clouds([queries[q] for q in mine], bs) if len(mine) else _empty_set(dev)
+    q_max = max(len(s_) for s_ in qshards)
+    order = shard_order(qshards)
+    descs = _all_gather_padded(dist, qs.desc, q_max, world)
+    desc_all = torch.cat([descs[r][: len(qshards[r])] for r in range(world)])[torch.from_numpy(order).to(qs.desc.device)]
+    stat = H.retrieval_stat(pipe, desc_all, cat.desc, best_match, table)
+    # 3. registration of the own queries
+    pos_idx = np.asarray(stat["top1_predict" if register_top1 else "gt"], dtype=np.int64)
+    local = H.register_queries(pipe, qs, mine, cat, pos_idx, syms, base_T, lib_T, force_gate, bs)
+    # 4. one result set, query order
+    per_query = {}
+    for name in C_.NAMES:
+        a = np.asarray(local[name])
+        a = a.reshape(len(a), -1).astype(np.float64 if a.dtype != np.float32 else np.float32)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        parts = _all_gather_padded(dist, t.cuda() if dist.get_backend() == "nccl" else t, q_max, world)
+        full = torch.cat([parts[r][: len(qshards[r])] for r in range(world)]).cpu().numpy()[order]
+        if name.startswith("Ts_est"):
+            per_query[name] = full.reshape(Q, 4, 4).astype(np.float32)
+        elif name == "sym_ransac_success":
+            per_query[name] = full[:, 0] != 0
+        else:
+            per_query[name] = full[:, 0]
+    if rank == 0 and cache_dir is not None:
+        C_.save_results(cache_dir, category, register_top1, per_query)
+    return H.finish_eval(stat, per_query, False)
+
+
+def _empty_set(dev):
+    return EmbeddedSet(torch.zeros((0, 16), device=dev), torch.zeros((0, 3), device=dev), [0],
+                       torch.zeros((0, 256), device=dev))

@@ -15,22 +15,29 @@ def predicted_rank(scan_feats, lib_feats, top_n):
 
 
 def scan2cad_retrieval_eval_rank(pred_rank, table, best_match, pos_n):
-    """scan2cad_retrieval_eval_dist (utils/retrieval.py:139-167) given the predicted ranking."""
+    """The statistics of scan2cad_retrieval_eval_dist (utils/retrieval.py:139-167) given the predicted ranking
+    (only its first pos_n columns are consumed), all queries at once:
+      precision   mean over queries of 100 * |pred[:pos_n] ∩ gt[:pos_n]| / pos_n,
+      top1_error  mean of table[pred[0], gt[0]],   top1_predict / gt  the first entries,
+    where gt = argsort(table[best_match]) (stable: ties -> smaller id).  The two means are LEFT-TO-RIGHT sums in
+    query order divided by Q -- what Python's sum() over the reference's per-query lists evaluates -- so the
+    figures equal the reference's to the last bit (np.cumsum adds sequentially; np.sum would add pairwise)."""
     table = np.asarray(table)
+    pred = np.asarray(pred_rank)[:, :max(int(pos_n), 1)]
     best_match = np.asarray(best_match).astype(np.int64)
-    gt_rank = np.argsort(table[best_match, :], 1, kind="stable")
-    precision, top1_error, top1_predict, gt = [], [], [], []
-    for g, p in zip(gt_rank, pred_rank):
-        positive = np.isin(p[:pos_n], g[:pos_n]).astype(np.int32)
-        precision.append(100.0 * np.sum(positive) / pos_n)
-        top1_error.append(table[p[0], g[0]])
-        top1_predict.append(int(p[0]))
-        gt.append(int(g[0]))
+    n_q, n_lib = len(best_match), table.shape[1]
+    gt_head = np.argsort(table[best_match, :], 1, kind="stable")[:, :max(int(pos_n), 1)]
+    rows = np.arange(n_q)[:, None]
+    member = np.zeros((n_q, n_lib), dtype=bool)          # member[q, c]: CAD c is among query q's pos_n GT neighbours
+    member[rows, gt_head[:, :pos_n]] = True
+    hits = member[rows, pred[:, :pos_n]].sum(axis=1)
+    precision = 100.0 * hits / pos_n
+    top1_error = table[pred[:, 0], gt_head[:, 0]]
     return {
-        "precision": sum(precision) / len(precision),
-        "top1_error": sum(top1_error) / len(top1_error),
-        "top1_predict": top1_predict,
-        "gt": gt,
+        "precision": float(np.cumsum(precision)[-1]) / n_q,
+        "top1_error": float(np.cumsum(top1_error)[-1]) / n_q,
+        "top1_predict": [int(v) for v in pred[:, 0]],
+        "gt": [int(v) for v in gt_head[:, 0]],
     }
 
 

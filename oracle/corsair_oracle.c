@@ -260,8 +260,102 @@ static void oc_jacobi4(double a[4][4], double v[4][4]) {
       }
 }
 
-/* ps, pt: n x 3 doubles.  R row-major 3x3, t 3. */
-void oc_rigid_fit(const double* ps, const double* pt, int n, double* R, double* t) {
+/* Largest eigenpair of the Horn matrix without iterating on the matrix (round 4; the same operation
+ * sequence as horn_qcp in corsair_amd/csrc/ransac.hip).  N is symmetric and traceless, so its characteristic
+ * polynomial is l^4 + c2 l^2 + c1 l + c0 with c2 = -2 |S|_F^2, c1 = -8 det S, c0 = det N (Theobald's QCP
+ * observation).  All four roots are real, so Halley's iteration started at the upper bound sqrt(3) |S|_F
+ * (>= sigma1 + sigma2 + sigma3 >= l_max) decreases monotonically onto the largest root with cubic order;
+ * it stops after the step whose size is below 1e-6 l (the next error is the cube of that).  The eigenvector
+ * is the row of adj(N - l I) with the largest diagonal entry (adj = kappa v v^T: that row is kappa v_k v
+ * with |v_k| >= 1/2).  The pair is ACCEPTED only when the iteration converged within 8 steps and
+ * P'(l) = prod(l - l_j) >= 0.02 l^3, i.e. the largest eigenvalue is well separated; otherwise (near-collinear
+ * samples, reflections with sigma2 = sigma3, S = 0, non-finite input: 3 in 10^5 ten-point samples of the bench
+ * workload) the caller runs the Jacobi solver above.  Measured on 5.4 M samples against LAPACK: eigenvector
+ * within 3.2e-12, eigenvalue within 4.3e-14 relative on the accepted ones.  Returns 1 when q is valid. */
+static int oc_horn_qcp(const double S[3][3], const double N[4][4], double q[4]) {
+  double f2 = 0.0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) f2 = fma(S[a][b], S[a][b], f2);
+  const double c2 = -2.0 * f2;
+  const double detS = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) -
+                      S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+                      S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+  const double c1 = -8.0 * detS;
+  /* 2x2 minors of rows (0,1) and (2,3): only the diagonal changes between N and N - l I */
+  const double u5 = N[0][2] * N[1][3] - N[0][3] * N[1][2];
+  const double w0 = N[2][0] * N[3][1] - N[2][1] * N[3][0];
+  double c0;
+  {
+    const double u0 = N[0][0] * N[1][1] - N[0][1] * N[1][0];
+    const double u1 = N[0][0] * N[1][2] - N[0][2] * N[1][0];
+    const double u2 = N[0][0] * N[1][3] - N[0][3] * N[1][0];
+    const double u3 = N[0][1] * N[1][2] - N[0][2] * N[1][1];
+    const double u4 = N[0][1] * N[1][3] - N[0][3] * N[1][1];
+    const double w1 = N[2][0] * N[3][2] - N[2][2] * N[3][0];
+    const double w2 = N[2][0] * N[3][3] - N[2][3] * N[3][0];
+    const double w3 = N[2][1] * N[3][2] - N[2][2] * N[3][1];
+    const double w4 = N[2][1] * N[3][3] - N[2][3] * N[3][1];
+    const double w5 = N[2][2] * N[3][3] - N[2][3] * N[3][2];
+    c0 = u0 * w5 - u1 * w4 + u2 * w3 + u3 * w2 - u4 * w1 + u5 * w0;
+  }
+  double lam = sqrt(3.0 * f2);
+  int conv = 0;
+  for (int it = 0; it < 8 && !conv; ++it) {
+    const double l2 = lam * lam;
+    const double P = fma(fma(l2 + c2, lam, c1), lam, c0);
+    const double dP = fma(fma(4.0, l2, 2.0 * c2), lam, c1);
+    const double ddP = fma(12.0, l2, 2.0 * c2);
+    const double d = (2.0 * P * dP) / fma(2.0 * dP, dP, -(P * ddP));
+    lam = lam - d;
+    conv = fabs(d) <= 1e-6 * lam; /* false for NaN */
+  }
+  {
+    const double l2 = lam * lam;
+    const double dP = fma(fma(4.0, l2, 2.0 * c2), lam, c1);
+    if (!(conv && dP >= 0.02 * (l2 * lam))) return 0;
+  }
+  const double m00 = N[0][0] - lam, m11 = N[1][1] - lam, m22 = N[2][2] - lam, m33 = N[3][3] - lam;
+  const double m01 = N[0][1], m02 = N[0][2], m03 = N[0][3], m12 = N[1][2], m13 = N[1][3], m23 = N[2][3];
+  const double u0 = m00 * m11 - m01 * m01;
+  const double u1 = m00 * m12 - m02 * m01;
+  const double u2 = m00 * m13 - m03 * m01;
+  const double u3 = m01 * m12 - m02 * m11;
+  const double u4 = m01 * m13 - m03 * m11;
+  const double w1 = m02 * m23 - m22 * m03;
+  const double w2 = m02 * m33 - m23 * m03;
+  const double w3 = m12 * m23 - m22 * m13;
+  const double w4 = m12 * m33 - m23 * m13;
+  const double w5 = m22 * m33 - m23 * m23;
+  /* the four rows of the adjugate (symmetric: the off-diagonal entries are computed once) */
+  const double a00 = m11 * w5 - m12 * w4 + m13 * w3;
+  const double a01 = -m01 * w5 + m02 * w4 - m03 * w3;
+  const double a02 = m13 * u5 - m23 * u4 + m33 * u3;
+  const double a03 = -m12 * u5 + m22 * u4 - m23 * u3;
+  const double a11 = m00 * w5 - m02 * w2 + m03 * w1;
+  const double a12 = -m03 * u5 + m23 * u2 - m33 * u1;
+  const double a13 = m02 * u5 - m22 * u2 + m23 * u1;
+  const double a22 = m03 * u4 - m13 * u2 + m33 * u0;
+  const double a23 = -m02 * u4 + m12 * u2 - m23 * u0;
+  const double a33 = m02 * u3 - m12 * u1 + m22 * u0;
+  int k = 0;
+  double best = fabs(a00);
+  if (fabs(a11) > best) { best = fabs(a11); k = 1; }
+  if (fabs(a22) > best) { best = fabs(a22); k = 2; }
+  if (fabs(a33) > best) { best = fabs(a33); k = 3; }
+  if (!(best > 0.0)) return 0;
+  if (k == 0) { q[0] = a00; q[1] = a01; q[2] = a02; q[3] = a03; }
+  else if (k == 1) { q[0] = a01; q[1] = a11; q[2] = a12; q[3] = a13; }
+  else if (k == 2) { q[0] = a02; q[1] = a12; q[2] = a22; q[3] = a23; }
+  else { q[0] = a03; q[1] = a13; q[2] = a23; q[3] = a33; }
+  return 1;
+}
+
+static int oc_force_jacobi = 0; /* tests: the fallback alone (ORACLE-side switch only) */
+void oc_rigid_fit_force_jacobi(int on) { oc_force_jacobi = on; }
+
+/* ps, pt: n x 3 doubles.  R row-major 3x3, t 3.  Returns the eigen-solver used: 0 = closed-form
+ * characteristic polynomial (oc_horn_qcp), 1 = Jacobi fallback. */
+int oc_rigid_fit2(const double* ps, const double* pt, int n, double* R, double* t) {
   double cs[3] = {0, 0, 0}, ct[3] = {0, 0, 0};
   for (int j = 0; j < n; ++j)
     for (int a = 0; a < 3; ++a) {
@@ -299,11 +393,17 @@ void oc_rigid_fit(const double* ps, const double* pt, int n, double* R, double* 
   N[2][1] = N[1][2];
   N[3][1] = N[1][3];
   N[3][2] = N[2][3];
-  oc_jacobi4(N, V);
-  int m = 0;
-  for (int c = 1; c < 4; ++c)
-    if (N[c][c] > N[m][m]) m = c;
-  double qw = V[0][m], qx = V[1][m], qy = V[2][m], qz = V[3][m];
+  double qv[4];
+  int path = 0;
+  if (oc_force_jacobi || !oc_horn_qcp(S, N, qv)) {
+    path = 1;
+    oc_jacobi4(N, V);
+    int m = 0;
+    for (int c = 1; c < 4; ++c)
+      if (N[c][c] > N[m][m]) m = c;
+    for (int r = 0; r < 4; ++r) qv[r] = V[r][m];
+  }
+  double qw = qv[0], qx = qv[1], qy = qv[2], qz = qv[3];
   const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
   qw = qw / qn;
   qx = qx / qn;
@@ -320,6 +420,11 @@ void oc_rigid_fit(const double* ps, const double* pt, int n, double* R, double* 
   R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
   for (int a = 0; a < 3; ++a)
     t[a] = ct[a] - (R[3 * a + 0] * cs[0] + R[3 * a + 1] * cs[1] + R[3 * a + 2] * cs[2]);
+  return path;
+}
+
+void oc_rigid_fit(const double* ps, const double* pt, int n, double* R, double* t) {
+  (void)oc_rigid_fit2(ps, pt, n, R, t);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -95,6 +95,9 @@ def load():
         lib.oc_chamfer_1dir.restype = c_double
         lib.oc_rng_indices.argtypes = [c_uint64, c_uint64, c_int, c_uint32, vp]
         lib.oc_rigid_fit.argtypes = [vp, vp, c_int, vp, vp]
+        lib.oc_rigid_fit2.argtypes = [vp, vp, c_int, vp, vp]
+        lib.oc_rigid_fit2.restype = c_int
+        lib.oc_rigid_fit_force_jacobi.argtypes = [c_int]
         lib.oc_ransac.argtypes = [vp, vp, c_int64, c_double, c_int, c_int, c_double, c_uint64, vp,
                                   POINTER(c_int32), POINTER(c_double), POINTER(c_int32)]
         lib.oc_ransac_batch.argtypes = [vp, vp, vp, c_int, c_double, c_int, c_int, c_double,
@@ -202,25 +205,35 @@ def rng_indices(seed, itr, n, m):
     return out
 
 
-def rigid_fit(ps, pt):
+def rigid_fit(ps, pt, return_path=False, force_jacobi=False):
+    """oc_rigid_fit2.  return_path: also the eigen-solver used (0 = characteristic polynomial + adjugate,
+    1 = Jacobi fallback); force_jacobi: the fallback alone (tests)."""
     lib = load()
     ps = np.ascontiguousarray(ps, dtype=np.float64)
     pt = np.ascontiguousarray(pt, dtype=np.float64)
     R = np.empty((3, 3), dtype=np.float64)
     t = np.empty(3, dtype=np.float64)
-    lib.oc_rigid_fit(_p(ps), _p(pt), ps.shape[0], _p(R), _p(t))
-    return R, t
+    lib.oc_rigid_fit_force_jacobi(1 if force_jacobi else 0)
+    try:
+        path = lib.oc_rigid_fit2(_p(ps), _p(pt), ps.shape[0], _p(R), _p(t))
+    finally:
+        lib.oc_rigid_fit_force_jacobi(0)
+    return (R, t, path) if return_path else (R, t)
 
 
-def ransac(src, tgt, max_corr, ransac_n=10, max_iter=100000, confidence=0.999, seed=0):
+def ransac(src, tgt, max_corr, ransac_n=10, max_iter=100000, confidence=0.999, seed=0, force_jacobi=False):
     lib = load()
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, dtype=np.float32)
     inl, it = c_int32(0), c_int32(0)
     rm = c_double(0.0)
-    lib.oc_ransac(_p(src), _p(tgt), src.shape[0], float(max_corr), ransac_n, max_iter,
-                  float(confidence), seed, _p(T), ctypes.byref(inl), ctypes.byref(rm),
-                  ctypes.byref(it))
+    lib.oc_rigid_fit_force_jacobi(1 if force_jacobi else 0)
+    try:
+        lib.oc_ransac(_p(src), _p(tgt), src.shape[0], float(max_corr), ransac_n, max_iter,
+                      float(confidence), seed, _p(T), ctypes.byref(inl), ctypes.byref(rm),
+                      ctypes.byref(it))
+    finally:
+        lib.oc_rigid_fit_force_jacobi(0)
     return T.reshape(4, 4), inl.value, rm.value, it.value
 
 

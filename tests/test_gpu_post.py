@@ -174,6 +174,39 @@ def test_ransac_bit_exact_vs_oracle(gpu, oracle_native):
     assert np.array_equal(T[3], np.eye(4, dtype=np.float32)) and inl[3] == 0
 
 
+def test_ransac_hypothesis_eigen_solver_paths_bit_exact(gpu, oracle_native, monkeypatch):
+    """k_ransac_hyp takes the largest eigenpair of the Horn matrix from its characteristic polynomial (horn_qcp) and
+    falls back to the Jacobi solver per lane when the eigenvalue is not well separated.  Both paths equal the oracle's
+    (oc_horn_qcp / oc_jacobi4) bit for bit: (a) problems whose samples are degenerate -- sources on a line, all sources
+    equal, half of the sources on a line (a few hypotheses per wave diverge into the fallback) -- under the default
+    switch; (b) every hypothesis through the fallback (CS_RANSAC_JACOBI=1 / force_jacobi)."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(23)
+    probs = [_corr_problem(rng, m, f, pose_id=30 + i) for i, (m, f) in enumerate([(2000, 0.3), (1200, 0.1), (800, 0.5), (1500, 0.2)])]
+    line = (np.outer(rng.uniform(-1, 1, 1200), [0.3, -0.5, 0.8]) + [0.1, 0.0, -0.2]).astype(np.float32)
+    probs[1] = (line, probs[1][1], None)
+    probs[2] = (np.tile(np.float32([[0.2, 0.1, -0.4]]), (800, 1)), probs[2][1], None)
+    half = probs[3][0].copy()
+    half[::2] = (np.outer(rng.uniform(-1, 1, 750), [0.6, 0.2, -0.7])).astype(np.float32)
+    probs[3] = (half, probs[3][1], None)
+    for src, tgt, _ in probs[1:3]:                       # these samples do take the fallback
+        idx = oracle_native.rng_indices(0, 5, 10, len(src))
+        assert oracle_native.rigid_fit(src[idx], tgt[idx], return_path=True)[2] == 1
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("CS_RANSAC_JACOBI", "1")
+        T, inl, rmse, iters = (t.cpu().numpy() for t in B.ransac_batch(S, D, off, 0.2, 10, 3000, 0.999, 0))
+        for p, (src, tgt, _) in enumerate(probs):
+            wT, winl, wrmse, wit = oracle_native.ransac(src, tgt, 0.2, 10, 3000, 0.999, 0, force_jacobi=force)
+            assert inl[p] == winl and iters[p] == wit, (force, p, inl[p], winl, iters[p], wit)
+            assert np.array_equal(T[p], wT), (force, p)
+            assert rmse[p] == pytest.approx(wrmse, rel=1e-12)
+
+
 @pytest.mark.parametrize("ransac_n", [3, 6, 17])
 def test_ransac_other_sample_sizes_bit_exact(gpu, oracle_native, ransac_n):
     """ransac_n other than the reference's 10 (Open3D's default is 6) goes through the run-time-sized

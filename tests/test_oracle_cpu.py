@@ -306,6 +306,48 @@ def test_rigid_fit_matches_svd_umeyama(oracle_native):
         assert abs(np.linalg.det(R) - 1) < 1e-12
 
 
+def test_rigid_fit_characteristic_polynomial_path_and_its_fallback(oracle_native):
+    """Round 4: the largest eigenpair of the Horn matrix comes from its characteristic polynomial (Halley from
+    sqrt(3)|S|_F, adjugate row) -- path 0 -- with the Jacobi solver as the fallback when the largest eigenvalue is
+    not well separated -- path 1.  Both agree with the SVD optimum where that is unique and with each other."""
+    rng = np.random.default_rng(17)
+    paths = []
+    for trial in range(3000):
+        n = 10 if trial % 3 else int(rng.integers(3, 12))
+        ps = rng.uniform(-1, 1, (n, 3))
+        pt = rng.uniform(-1, 1, (n, 3)) if trial % 2 else ps @ _rot(rng).T + rng.normal(0, 0.05, (n, 3)) + rng.uniform(-1, 1, 3)
+        R, t, path = oracle_native.rigid_fit(ps, pt, return_path=True)
+        paths.append(path)
+        Rj, tj = oracle_native.rigid_fit(ps, pt, force_jacobi=True)
+        cs, ct = ps.mean(0), pt.mean(0)
+        U, S, Vt = np.linalg.svd((pt - ct).T @ (ps - cs))
+        d = np.sign(np.linalg.det(U) * np.linalg.det(Vt))
+        sep = (S[1] + d * S[2]) / S[0]                    # (l1 - l2) / 2 sigma1: how unique the optimum is
+        if sep > 1e-3:
+            Rw = U @ np.diag([1, 1, d]) @ Vt
+            tol = 1e-11 / sep
+            assert np.abs(R - Rw).max() < tol and np.abs(Rj - Rw).max() < tol, (trial, path, sep)
+            assert np.abs(t - (ct - Rw @ cs)).max() < 4 * tol
+        assert abs(np.linalg.det(R) - 1) < 1e-12
+    assert np.mean(paths) < 0.01                          # the fallback is rare on generic samples
+    # degenerate samples take the fallback and give what the Jacobi solver gives, bit for bit
+    line = np.outer(np.linspace(-1, 1, 10), [0.3, -0.5, 0.8])
+    same = np.tile([[0.2, 0.1, -0.4]], (10, 1))
+    tgt = rng.uniform(-1, 1, (10, 3))
+    for ps in (line, same):
+        R, t, path = oracle_native.rigid_fit(ps, tgt, return_path=True)
+        Rj, tj = oracle_native.rigid_fit(ps, tgt, force_jacobi=True)
+        assert path == 1 and np.array_equal(R, Rj) and np.array_equal(t, tj)
+
+
+def _rot(rng):
+    q = rng.standard_normal(4)
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
 def test_ransac_oracle_recovers_pose_and_exits_early(oracle_native):
     from corsair_amd import synth
 

@@ -184,3 +184,123 @@ def test_merge_topk_orders_by_distance_then_id():
     ids, d2 = sharding.merge_topk([d2a, d2b], [ida, idb], 4)
     assert ids.tolist() == [[7, 3, 9, 10]] and d2.tolist() == [[1.0, 2.0, 2.0, 2.0]]
     assert sharding.catalog_shard(10, 3, 4) == (9, 10) and sharding.catalog_shard(10, 0, 4) == (0, 3)
+
+
+# ---- the whole evaluation on 2 ranks ends in ONE result set equal to the single-rank run ----------
+class _FakePipe:
+    """Duck-typed harness.Pipeline without a GPU: every output is a deterministic function of the INPUT item only
+    (cloud contents, global anchor ids), like the real path (eval-mode network, per-query anchor seeds) -- what the
+    sharded evaluation relies on.  Exercises sharding, the three gathers and the re-ordering, not the kernels."""
+
+    def __init__(self):
+        from corsair_amd import harness
+
+        self.cfg = harness.Config(batch_size=4)
+        self.device = torch.device("cpu")
+
+    def voxel_counts(self, clouds):
+        return [len(np.unique(np.floor(np.asarray(c) / self.cfg.voxel_size).astype(np.int64), axis=0)) for c in clouds]
+
+    def embed_clouds(self, clouds, batch_size=None):
+        from corsair_amd.harness import EmbeddedSet
+
+        F, O, off, D = [], [], [0], []
+        for c in clouds:
+            c = np.asarray(c, np.float64)
+            n = 5 + int(abs(c[0, 0]) * 1000) % 7
+            F.append(torch.from_numpy(np.tile(c[:n, :1], (1, 16)).astype(np.float32)))
+            O.append(torch.from_numpy(c[:n].astype(np.float32)))
+            off.append(off[-1] + n)
+            d = np.cos(np.arange(256) * (1.0 + c[:32].sum()))
+            D.append(torch.from_numpy((d / np.linalg.norm(d)).astype(np.float32))[None])
+        return EmbeddedSet(torch.cat(F), torch.cat(O), off, torch.cat(D))
+
+    def retrieve(self, q, x, k):
+        d2 = ((q.double()[:, None, :] - x.double()[None, :, :]) ** 2).sum(-1).numpy()
+        return torch.from_numpy(np.argsort(d2, axis=1, kind="stable")[:, :k])
+
+    def register(self, queries, cads, syms, anchor_ids=None, force_gate=False, **_):
+        import types
+
+        from corsair_amd import synth
+
+        P = len(queries)
+        Tr, Tb, cr, cb, ok = [], [], [], [], []
+        for p in range(P):
+            qs = float(queries.F[queries.offsets[p]:queries.offsets[p + 1]].double().sum())
+            cs = float(cads.F[cads.offsets[p]:cads.offsets[p + 1]].double().sum())
+            a = anchor_ids[p][0] * 0.37 + qs + 2.0 * cs + int(syms[p])
+            T = np.eye(4)
+            T[:3, :3] = synth.euler2mat(a, 0.5 * a, 0.25 * a)
+            T[:3, 3] = [np.sin(a), np.cos(a), 0.1]
+            Tr.append(T.astype(np.float32))
+            Tb.append((T @ T).astype(np.float32))
+            cr.append(abs(np.sin(a)) + 0.2)
+            cb.append(abs(np.sin(a)) * 0.5)
+            ok.append(anchor_ids[p][1] % 3 != 0)
+        return types.SimpleNamespace(T_ransac=torch.from_numpy(np.stack(Tr)), T_best=torch.from_numpy(np.stack(Tb)),
+                                     cd_ransac=torch.tensor(cr, dtype=torch.float64),
+                                     cd_best=torch.tensor(cb, dtype=torch.float64), ok=np.asarray(ok))
+
+
+def _eval_inputs():
+    from corsair_amd import synth
+
+    rng = np.random.default_rng(12)
+    C, Q = 13, 11
+    catalog = [rng.uniform(-1, 1, (200 + 40 * (c % 5), 3)).astype(np.float32) for c in range(C)]
+    queries = [synth.apply_pose(catalog[q % C][:150 + 20 * (q % 4)], synth.random_pose(q), np.float64) for q in range(Q)]
+    table = rng.random((C, C))
+    table = table + table.T
+    np.fill_diagonal(table, 0.0)
+    best_match = np.arange(Q) % C
+    base_T = np.stack([synth.random_pose(q) for q in range(Q)])
+    lib_T = np.stack([np.eye(4)] * C)
+    syms = np.ones(C, np.int32)
+    syms[[2, 7]] = [2, 4]
+    return catalog, queries, best_match, table, base_T, lib_T, syms
+
+
+def _eval_worker(rank, world, port, out_dir):
+    import pickle
+
+    import torch.distributed as dist
+
+    from corsair_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        catalog, queries, best_match, table, base_T, lib_T, syms = _eval_inputs()
+        res = sharding.run_eval_sharded(_FakePipe(), dist, rank, world, catalog, queries, best_match, table, base_T,
+                                        lib_T, syms, "chair", True, cache_dir=os.path.join(out_dir, "cache"))
+        with open(os.path.join(out_dir, f"eval{rank}.pkl"), "wb") as f:
+            pickle.dump((res.stat, res.per_query, res.report), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluation_world2_ends_in_the_single_rank_result(tmp_path):
+    """evaluation.py:207-441 on 2 ranks (sharding.run_eval_sharded): catalog and queries dealt out by voxel count, the
+    embedded catalog, the query descriptors and the nine per-query arrays gathered; both ranks hold the result of
+    the single-rank harness.run_eval bit for bit, and the nine cache files are written once, by rank 0."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    from corsair_amd import cache, harness
+
+    mp.spawn(_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    catalog, queries, best_match, table, base_T, lib_T, syms = _eval_inputs()
+    want = harness.run_eval(_FakePipe(), catalog, queries, best_match, table, base_T, lib_T, syms, "chair", True)
+    for r in range(2):
+        with open(tmp_path / f"eval{r}.pkl", "rb") as f:
+            stat, per_query, report = pickle.load(f)
+        assert stat == want.stat and report == want.report
+        for k in cache.NAMES:
+            assert per_query[k].dtype == want.per_query[k].dtype and np.array_equal(per_query[k], want.per_query[k]), k
+    loaded = cache.load_results(str(tmp_path / "cache"), "chair", True)
+    for k in cache.NAMES:
+        assert np.array_equal(loaded[k], want.per_query[k]), k
+    assert sorted(p.name for p in (tmp_path / "cache").iterdir()) == sorted(f"{n}_chair_top1.npy" for n in cache.NAMES)
