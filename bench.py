@@ -78,6 +78,11 @@ def parse():
                     help="the CPU sample stops once it has run this many RANSAC problems (~1.9 s each on 16 cores)")
     ap.add_argument("--cpu-catalog", type=int, default=64,
                     help="catalog subset the CPU baseline retrieves against (SURVEY 8d: 64)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the driver's contract): 32 queries per rank and step.  strong: chair / table only, one "
+                         "step = one WHOLE evaluation of the query pool (993 / 291) spread over the ranks, results gathered "
+                         "to one result set (configs[3] as time to solution)")
+    ap.add_argument("--queries", type=int, default=0, help="--scaling strong: size of the query pool (default: the category's)")
     ap.add_argument("--catalog", type=int, default=0, help="catalog size (default: the workload's)")
     ap.add_argument("--desc-dim", type=int, default=256, help="stress: descriptor width (256 or 512)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -453,6 +458,84 @@ class RegistrationWorkload:
 
 
 # =====================================================================================================
+class StrongEvalWorkload:
+    """configs[3] as TIME TO SOLUTION (`--scaling strong`): one step = ONE whole evaluation of the category's query pool
+    (993 chair / 291 table queries) spread over all ranks -- sharding.run_eval_sharded = evaluation.py:207-441: queries
+    dealt out by voxel count, embedded, descriptors all-gathered, retrieval statistics, every rank registers its own
+    queries, the nine per-query arrays all-gathered into query order, rank 0 aggregates.  The embedded catalog is
+    made (sharded + one all-gather) once before the timed region, like `lib_desc` in the reference; value = Q / step."""
+    collective_in_step = True
+    scaling = "strong"
+
+    def __init__(self, ctx, kind):
+        from corsair_amd import harness, synth
+
+        self.ctx, self.kind = ctx, kind
+        self.cfg = harness.Config()
+        self.C = ctx.args.catalog or sum(SYM_HISTOGRAM[kind].values())
+        self.Q = ctx.args.queries or QUERY_POOL[kind]
+        self.sd, self.emb = synth.make_state_dicts(self.cfg.random_seed)
+        self.pipe = harness.Pipeline(self.sd, self.emb, device=ctx.dev, config=self.cfg)
+        self.sym = sym_labels(kind, self.C)
+        self.results = []
+        self.units_per_step = self.Q          # of the WHOLE job (all ranks together)
+
+    def setup(self):
+        import torch
+
+        from corsair_amd import sharding, synth
+
+        ctx, cfg, C, Q = self.ctx, self.cfg, self.C, self.Q
+        t0 = time.time()
+        catalog = [synth.make_cloud(c, 15000)[: cfg.n_points] for c in range(C)]
+        self.catalog = sharding.embed_catalog_sharded(self.pipe, ctx.dist, ctx.rank, ctx.world, catalog)
+        torch.cuda.synchronize()
+        self.catalog_embed_s = time.time() - t0
+        self.queries, self.q_T = [], []
+        for q in range(Q):
+            T = synth.random_pose(q, max_trans=0.0)
+            self.queries.append(synth.apply_pose(synth.make_cloud(q % C, 15000)[15000 - cfg.n_points:], T, np.float64))
+            self.q_T.append(T)
+        self.best_match = np.arange(Q) % C
+        rng = np.random.Generator(np.random.Philox(key=0x7AB1E, counter=C))
+        t = rng.random((C, C))
+        self.table = t + t.T                  # stands in for configs/*_scan2cad.npy (pairwise Chamfer of the CADs)
+        np.fill_diagonal(self.table, 0.0)
+        self.lib_T = np.stack([np.eye(4)] * C)
+        ctx.log("setup done: strong-scaling %s evaluation, catalog %d embedded+gathered in %.2fs, %d queries"
+                % (self.kind, C, self.catalog_embed_s, Q))
+
+    def step(self, b):
+        from corsair_amd import sharding
+
+        res = sharding.run_eval_sharded(self.pipe, self.ctx.dist, self.ctx.rank, self.ctx.world, self.catalog, self.queries,
+                                        self.best_match, self.table, np.stack(self.q_T), self.lib_T, self.sym, self.kind,
+                                        True, None, True)
+        self.results.append((b, res))
+
+    def same_results(self, a, b):
+        return all(np.array_equal(a[1].per_query[k], b[1].per_query[k]) for k in a[1].per_query)
+
+    def solo_env(self):
+        return None
+
+    def config(self, steps):
+        res = self.results[-1][1]
+        idx = {"chair": 1, "table": 2}[self.kind]
+        return {"workload": "configs[3] (strong scaling of configs[%d]): ONE Scan2CAD-%s-shaped evaluation per step -- %d queries "
+                            "against a %d-CAD catalog spread over the ranks by voxel count, retrieval statistics, sym_pose "
+                            "RANSAC 100000x10, per-query results gathered to one result set (evaluation.py:207-441)"
+                            % (idx, self.kind, self.Q, self.C),
+                "queries_per_step": self.Q, "catalog": self.C, "catalog_embed_s": self.catalog_embed_s,
+                "rre_mean_deg": res.sym["rre_mean_deg"], "rre_15": res.sym["rre_15"],
+                "precision_at_M": res.stat["precision"], "sym_success_rate": res.sym_success_rate,
+                "all_steps_identical": all(self.same_results(self.results[0], r) for r in self.results[1:])}
+
+    def extras(self, out):
+        pass
+
+
+# =====================================================================================================
 class StressWorkload:
     """configs[4]: batch-64 forward on 15k-pt clouds @ 2 cm + top-10 against a 10^6-descriptor catalog.
     One step = 16 forward batches (1024 clouds) + the proportional slice of the 10^6 x 10^6 top-10
@@ -769,6 +852,18 @@ def timed_region(ctx, wl, runner, warmup, steps):
     return elapsed, own_elapsed, fam
 
 
+def overlap_probe_allowed(depth, steps, disabled, world, wl):
+    """The extra `batches_in_flight` pass runs three batches on three host threads.  With a collective inside the step
+    on several ranks the worker threads of a rank would issue their all-gathers in an order of their own and the
+    ranks' collectives would no longer pair up (the crash fixed in 86a7de4): never in that case.  Strong-scaling steps
+    are whole evaluations, not independent batches: never there either."""
+    if depth != 1 or steps < 2 or disabled:
+        return False
+    if getattr(wl, "scaling", "weak") == "strong":
+        return False
+    return not (world > 1 and getattr(wl, "collective_in_step", False))
+
+
 LEG_STEPS, LEG_WARMUP = 8, 2
 
 
@@ -813,7 +908,13 @@ def main():
     from corsair_amd import _lib
 
     ctx = Ctx(args)
-    wl = StressWorkload(ctx) if args.workload == "stress" else RegistrationWorkload(ctx, args.workload)
+    if args.scaling == "strong":
+        if args.workload == "stress":
+            sys.stderr.write("[bench] --scaling strong is the chair / table evaluation; the stress workload is weak-scaled\n")
+            sys.exit(2)
+        wl = StrongEvalWorkload(ctx, args.workload)
+    else:
+        wl = StressWorkload(ctx) if args.workload == "stress" else RegistrationWorkload(ctx, args.workload)
     wl.setup()
 
     # Query batches are independent: `--pipeline D` keeps D of them in flight, each driven by its own
@@ -861,8 +962,7 @@ def main():
     overlap = None
     # (not with a collective inside the step on several ranks: the worker threads of a rank would issue their
     # all-gathers in an order of their own and the ranks' collectives would no longer pair up)
-    collective_step = ctx.world > 1 and getattr(wl, "collective_in_step", False)
-    if depth == 1 and args.steps >= 2 and not args.no_overlap_probe and not collective_step:
+    if overlap_probe_allowed(depth, args.steps, args.no_overlap_probe, ctx.world, wl):
         seq_results = {r[0]: r for r in wl.results}
         run_steps(0, min(3, args.warmup + args.steps), depth=3)   # untimed: every worker's first step (cold scratch)
         wl.results.clear()
@@ -883,7 +983,8 @@ def main():
 
     cfg = wl.config(args.steps)   # every rank (accuracy bookkeeping of its own queries)
     if ctx.rank == 0:
-        total_units = args.steps * wl.units_per_step * ctx.world
+        strong = getattr(wl, "scaling", "weak") == "strong"
+        total_units = args.steps * wl.units_per_step * (1 if strong else ctx.world)
         cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": depth})
         out = {
             "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD %s"
@@ -895,7 +996,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -922,11 +1023,13 @@ def main():
                 "note": "same K batches again with three host threads x three HIP streams (python bench.py --pipeline 3); "
                         "not the contract number (the live per-launch times of `roofline` would include the "
                         "neighbours' kernels)"}
-        if ctx.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = wl.cpu_baseline()
-        if ctx.world == 1 and args.workload == "chair" and not args.no_extra_workloads:
-            # configs[2] and configs[4] under the same clock as the headline (short legs, same measurement)
+        if ctx.world == 1 and args.workload == "chair" and not strong and not args.no_extra_workloads:
+            # configs[2] and configs[4] under the same clock as the headline (short legs, same measurement).  BEFORE the
+            # CPU baseline: after it the table leg measured 429 instead of 568 queries/s on the same box (the oracle's
+            # OpenMP / BLAS worker threads keep the host cores busy for a while after their last parallel region)
             out["workloads"] = {name: extra_workload_leg(ctx, args, name) for name in ("table", "stress")}
+        if ctx.world == 1 and not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
+            out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out))
     if ctx.dist is not None:
         ctx.dist.barrier()

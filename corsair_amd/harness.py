@@ -81,8 +81,14 @@ class Pipeline:
         origin = xyz[keep].to(torch.float32)
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=xyz.device)
         out, feat8, maps = self.engine.forward(grid, feats)
-        desc = self.engine.embed(feat8, maps, len(offsets) - 1)
-        return EmbeddedSet(out, origin, out_off, desc)
+        return EmbeddedSet(out, origin, out_off, self._descriptors(feat8, maps, len(offsets) - 1))
+
+    def _descriptors(self, feat8, maps, n):
+        """Global descriptors [n,256]; a checkpoint without `embedding_state_dict` (evaluation-shapenet.py:283-289 loads
+        the network only) gives an empty [n,0] block: registration needs none, retrieval would fail loudly."""
+        if self.engine.emb is None:
+            return torch.zeros((n, 0), dtype=torch.float32, device=feat8.device)
+        return self.engine.embed(feat8, maps, n)
 
     def embed_groups(self, groups, voxel_size=None):
         """One forward over several groups of clouds that differ in type: groups = [(xyz, offsets), ...], each
@@ -103,8 +109,7 @@ class Pipeline:
         grid = torch.cat(grids)
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=grid.device)
         out, feat8, maps = self.engine.forward(grid, feats)
-        desc = self.engine.embed(feat8, maps, base)
-        return EmbeddedSet(out, torch.cat(origins), out_off, desc)
+        return EmbeddedSet(out, torch.cat(origins), out_off, self._descriptors(feat8, maps, base))
 
     def embed_clouds(self, clouds, batch_size=None):
         """clouds: list of f32 or f64 [n,3] NumPy arrays (host), one type per call: a cloud is quantised in
@@ -358,3 +363,110 @@ class SyntheticScan2CAD:
         canonical frame (lib_T = identity, like the bench's T1)."""
         return (self.catalog, self.queries, np.asarray(self.query_cad), np.stack(self.query_T),
                 np.stack([np.eye(4)] * len(self.catalog)), self.sym)
+
+
+# ---- file-level entry: `python -m corsair_amd.harness` (evaluation.py:68-129,195-201) -----------------------------------
+def load_cloud_dir(path, n_points, what):
+    """Sorted *.npy files of a directory, first n_points rows each (load_raw_pc, utils/preprocess.py:27-29 through
+    datasets/Reader.py:75-86), in the type they are stored in.  Returns (names, clouds)."""
+    import os
+
+    names = sorted(f for f in os.listdir(path) if f.endswith(".npy"))
+    if not names:
+        raise FileNotFoundError(f"{what}: no .npy cloud in {path}")
+    clouds = []
+    for f in names:
+        a = np.load(os.path.join(path, f))
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError(f"{what}: {f} is not an [n,3] cloud (shape {a.shape})")
+        a = np.ascontiguousarray(a[:n_points, :3])
+        clouds.append(a if a.dtype in (np.float32, np.float64) else a.astype(np.float32))
+    return names, clouds
+
+
+def read_sym_labels(path, names):
+    """`<cad path> <label>` per line (configs/*_scan2cad_rot_sym_label.txt, read at evaluation.py:175-179): matched to
+    the catalog files by basename when every name occurs, by line order otherwise."""
+    import os
+
+    rows = [ln.split() for ln in open(path) if ln.strip()]
+    by_name = {os.path.basename(r[0]): int(r[-1]) for r in rows}
+    if all(n in by_name for n in names):
+        return np.asarray([by_name[n] for n in names], np.int32)
+    if len(rows) != len(names):
+        raise ValueError(f"{path}: {len(rows)} labels for {len(names)} catalog clouds")
+    return np.asarray([int(r[-1]) for r in rows], np.int32)
+
+
+def build_parser():
+    import argparse
+
+    ap = argparse.ArgumentParser(
+        prog="python -m corsair_amd.harness",
+        description="CORSAIR evaluation on the MI355X path from FILES: a reference checkpoint (utils/ckpts.py format) and "
+                    "directories of .npy clouds; the counterpart of `python evaluation.py` (evaluation.py:68-129) with the "
+                    "Scan2CAD annotation parsing (out of scope, SURVEY 2) replaced by plain arrays.")
+    ap.add_argument("--checkpoint", "--ckpt", required=True, help="torch.save dict with state_dict / embedding_state_dict "
+                                                                  "(evaluation.py:195-201)")
+    ap.add_argument("--catalog-dir", required=True, help="CAD clouds, one [n,3] .npy each (sorted by name = catalog index)")
+    ap.add_argument("--query-dir", required=True, help="scan clouds, one [n,3] .npy each (sorted by name = query index)")
+    ap.add_argument("--category", default="table", choices=["table", "chair"])
+    ap.add_argument("--query-poses", help=".npy [Q,4,4] or [Q,k,4,4] (configs/fix_trans.npy: element [:,0]) applied to the "
+                                          "queries with apply_transform (f64) before quantisation; default: none")
+    ap.add_argument("--lib-poses", help=".npy [C,4,4] ground-truth poses of the CADs (`pos_T`); default identity")
+    ap.add_argument("--best-match", help=".npy int [Q]: annotated CAD index of every query; default: query i -> i mod C")
+    ap.add_argument("--table", help=".npy f64 [C,C] pairwise Chamfer of the catalog (configs/<catid>_scan2cad.npy); "
+                                    "default: computed from the first 2000 points of every CAD (utils/pc_dist.py)")
+    ap.add_argument("--sym-labels", help="`<path> <label>` per line (configs/<catid>_scan2cad_rot_sym_label.txt); default 1")
+    ap.add_argument("--cache-dir", default=None, help="load / save the nine result files (evaluation.py:390-441)")
+    ap.add_argument("--register-gt", action="store_false", dest="register_top1", help="register the annotated CAD")
+    ap.add_argument("--ignore-cache", action="store_true")
+    ap.add_argument("--n-points", type=int, default=10000)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--ransac-max-iter", type=int, default=100000)
+    ap.add_argument("--device", default="cuda", choices=["cuda"], help="there is no CPU path")
+    return ap
+
+
+def main(argv=None):
+    """Returns the EvalResult (and prints the log block of evaluation.py:359-383)."""
+    from . import synth
+    from .utils import ckpts, pc_dist
+
+    a = build_parser().parse_args(argv)
+    sd, esd = ckpts.load_state_dicts(a.checkpoint)
+    if esd is None:
+        raise SystemExit("checkpoint has no embedding_state_dict: retrieval needs the descriptor head (evaluation.py:199)")
+    cfg = Config(n_points=a.n_points, batch_size=a.batch_size, ransac_max_iter=a.ransac_max_iter)
+    pipe = Pipeline(sd, esd, device=a.device, config=cfg)
+    cad_names, catalog = load_cloud_dir(a.catalog_dir, a.n_points, "catalog")
+    _, queries = load_cloud_dir(a.query_dir, a.n_points, "queries")
+    C, Q = len(catalog), len(queries)
+    base_T = np.stack([np.eye(4)] * Q)
+    if a.query_poses:
+        P = np.load(a.query_poses)
+        base_T = np.asarray(P[:Q, 0] if P.ndim == 4 else P[:Q], np.float64)
+        if base_T.shape != (Q, 4, 4):
+            raise SystemExit(f"--query-poses: need {Q} 4x4 poses, got {P.shape}")
+        queries = [synth.apply_pose(q, T, np.float64) for q, T in zip(queries, base_T)]     # apply_transform: f64
+    lib_T = np.asarray(np.load(a.lib_poses), np.float64) if a.lib_poses else np.stack([np.eye(4)] * C)
+    best_match = np.load(a.best_match).astype(np.int64) if a.best_match else np.arange(Q) % C
+    syms = read_sym_labels(a.sym_labels, cad_names) if a.sym_labels else np.ones(C, np.int32)
+    if a.table:
+        table = np.array(np.load(a.table), np.float64)
+    else:
+        table = pc_dist.compute_dist([c[:2000] for c in catalog])
+    np.fill_diagonal(table, 0.0)                                     # datasets/ScannetDataset.py:65-66
+    if table.shape != (C, C) or len(best_match) != Q or len(lib_T) != C:
+        raise SystemExit(f"shape mismatch: table {table.shape}, best_match {len(best_match)}, lib poses {len(lib_T)} "
+                         f"for C = {C}, Q = {Q}")
+    res = run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, a.category, a.register_top1,
+                   a.cache_dir, a.ignore_cache, False, a.batch_size)
+    print(f"category: {a.category}")
+    print(f"precision: {res.stat['precision']}\ntop1_error: {res.stat['top1_error']}")
+    print(res.report)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -160,3 +160,91 @@ def threshold_table(results, rre_deg=(5, 15, 45), rte=(0.02, 0.05, 0.10, 0.15)):
         out[tag] = {**{f"rre<={d}": float(np.mean(r <= np.deg2rad(d))) for d in rre_deg},
                     **{f"rte<={v}": float(np.mean(t <= v)) for v in rte}}
     return out
+
+
+# ---- file-level entry: `python -m corsair_amd.shapenet_eval` (evaluation-shapenet.py:158-240,277-380) ---------------------
+CSV_COLUMNS = ("model", "pose_idx", "symmetry_label", "sym_success", "rte_sym", "rre_sym", "cd_sym", "rte_ransac",
+               "rre_ransac", "cd_ransac")            # evaluation-shapenet.py:323-334
+
+
+def write_results(results, names, csv_file, npz_file):
+    """results-*.csv with the reference's columns and poses-*.npz with poses_gt / poses_pred_sym / poses_pred_ransac
+    (evaluation-shapenet.py:345-380)."""
+    import csv
+
+    with open(csv_file, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(CSV_COLUMNS)
+        for r in results:
+            w.writerow([names[r["model"]], r["pose_idx"], r["symmetry_label"], r["sym_success"], r["rte_sym"], r["rre_sym"],
+                        r["chamfer_dist_sym"], r["rte_ransac"], r["rre_ransac"], r["chamfer_dist_ransac"]])
+    with open(npz_file, "wb") as f:
+        np.savez(f, poses_gt=np.stack([r["pose_gt"] for r in results]),
+                 poses_pred_sym=np.stack([r["T_est_sym"] for r in results]),
+                 poses_pred_ransac=np.stack([r["T_est_ransac"] for r in results]))
+
+
+def summary(results):
+    """The three lines evaluation-shapenet.py:226-234 prints."""
+    r = {k: np.asarray([x[k] for x in results]) for k in ("rte_sym", "rte_ransac", "rre_sym", "rre_ransac")}
+    n, five = len(results), np.deg2rad(5)
+    lines = []
+    for title, fs, fr in (("RTE <= 0.02", r["rte_sym"] <= 0.02, r["rte_ransac"] <= 0.02),
+                          ("RRE <= 5 deg", r["rre_sym"] <= five, r["rre_ransac"] <= five),
+                          ("RTE <= 0.02 & RRE <= 5 deg", (r["rte_sym"] <= 0.02) & (r["rre_sym"] <= five),
+                           (r["rte_ransac"] <= 0.02) & (r["rre_ransac"] <= five))):
+        lines.append(f"{title}: sym: {fs.sum() / n:.4f}, ransac: {fr.sum() / n:.4f}")
+    return "\n".join(lines)
+
+
+def main(argv=None):
+    import argparse
+    import os
+
+    from . import harness
+    from .utils import ckpts
+
+    ap = argparse.ArgumentParser(prog="python -m corsair_amd.shapenet_eval",
+                                 description="Registration evaluation with synthetic poses on a directory of .npy clouds "
+                                             "(evaluation-shapenet.py:158-240): writes results-*.csv / poses-*.npz")
+    ap.add_argument("--data-dir", help="directory of [n,3] .npy clouds; or --shapenet-root + --category as in the reference")
+    ap.add_argument("--shapenet-root")
+    ap.add_argument("--category", default="chair", choices=["chair", "table"])
+    ap.add_argument("--n-models", type=int, default=1)
+    ap.add_argument("--n-poses-per-model", type=int, default=10)
+    ap.add_argument("--max-roll-deg", type=float, default=360)
+    ap.add_argument("--max-pitch-deg", type=float, default=360)
+    ap.add_argument("--max-yaw-deg", type=float, default=360)
+    ap.add_argument("--max-translation", type=float, default=1.0)
+    ap.add_argument("--model-ckpt", "--ckpt", required=True, dest="ckpt")
+    ap.add_argument("--random-seed", type=int, default=0)
+    ap.add_argument("--ransac-max-iter", type=int, default=100000)
+    ap.add_argument("--out-dir", default=".")
+    ap.add_argument("--device", default="cuda", choices=["cuda"])
+    a = ap.parse_args(argv)
+    if not a.data_dir:
+        if not a.shapenet_root:
+            raise SystemExit("give --data-dir, or --shapenet-root with --category")
+        a.data_dir = os.path.join(a.shapenet_root, {"chair": "03001627", "table": "04379243"}[a.category], "test")
+    files = sorted(f for f in os.listdir(a.data_dir) if f.endswith(".npy"))
+    rng = np.random.default_rng(a.random_seed)
+    if 0 < a.n_models < len(files):                                   # evaluation-shapenet.py:200-203
+        files = sorted(rng.choice(files, a.n_models, replace=False).tolist())
+    clouds = [np.load(os.path.join(a.data_dir, f)) for f in files]
+    sd, esd = ckpts.load_state_dicts(a.ckpt)
+    pipe = harness.Pipeline(sd, esd, device=a.device)
+    cfg = Config(random_seed=a.random_seed, n_poses_per_model=a.n_poses_per_model, max_roll_deg=a.max_roll_deg,
+                 max_pitch_deg=a.max_pitch_deg, max_yaw_deg=a.max_yaw_deg, max_translation=a.max_translation,
+                 ransac_max_iter=a.ransac_max_iter)
+    results = evaluate(pipe, clouds, cfg)
+    postfix = f"shapenet-seed{a.random_seed}-{a.category}-{len(files)}-{a.n_poses_per_model}"
+    os.makedirs(a.out_dir, exist_ok=True)
+    csv_file = os.path.join(a.out_dir, f"results-{postfix}.csv")
+    npz_file = os.path.join(a.out_dir, f"poses-{postfix}.npz")
+    write_results(results, files, csv_file, npz_file)
+    print(summary(results))
+    return results, csv_file, npz_file
+
+
+if __name__ == "__main__":
+    main()

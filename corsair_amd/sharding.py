@@ -189,6 +189,16 @@ def voxel_balanced_shards(dist, pipe, clouds, rank, world):
     return balanced_shards(all_gather_counts(dist, mine, counts, n, world), world)
 
 
+def embed_catalog_sharded(pipe, dist, rank, world, catalog, batch_size=None):
+    """The catalog pass of a multi-GPU evaluation: clouds dealt to the ranks by voxel count, embedded, ONE all-gather
+    (RCCL over xGMI) of descriptors + voxel features + origins; returns the full catalog in item order on every rank."""
+    if dist is None or world == 1:
+        return pipe.embed_clouds(list(catalog), batch_size)
+    shards = voxel_balanced_shards(dist, pipe, catalog, rank, world)
+    local = pipe.embed_clouds([catalog[c] for c in shards[rank]], batch_size) if shards[rank] else _empty_set(pipe.device)
+    return gather_catalog(dist, local, len(catalog), world, shards)
+
+
 def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, table, base_T, lib_T, syms, category="chair",
                      register_top1=True, cache_dir=None, force_gate=False, batch_size=None):
     """harness.run_eval on `world` ranks (one process per GPU), strong scaling: ONE evaluation of all Q queries.
@@ -212,13 +222,11 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
     cfg = pipe.cfg
     bs = batch_size or cfg.batch_size
     dev = pipe.device
-    C, Q = len(catalog), len(queries)
+    Q = len(queries)
     best_match = np.asarray(best_match).astype(np.int64)
     syms = np.asarray(syms)
-    # 1. catalog
-    cshards = voxel_balanced_shards(dist, pipe, catalog, rank, world)
-    cat_local = pipe.embed_clouds([catalog[c] for c in cshards[rank]], bs) if cshards[rank] else _empty_set(dev)
-    cat = gather_catalog(dist, cat_local, C, world, cshards)
+    # 1. catalog (an EmbeddedSet = already embedded and gathered, e.g. once for several evaluations)
+    cat = catalog if isinstance(catalog, EmbeddedSet) else embed_catalog_sharded(pipe, dist, rank, world, catalog, bs)
     # 2. queries
     qshards = voxel_balanced_shards(dist, pipe, queries, rank, world)
     mine = np.asarray(qshards[rank], dtype=np.int64)

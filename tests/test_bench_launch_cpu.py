@@ -70,3 +70,22 @@ def test_table_label_histogram():
     chair = bench.sym_labels("chair", 652)
     assert (chair == 1).sum() == 650 and (chair == 4).sum() == 2
     assert len(bench.sym_labels("table", 64)) == 64
+
+
+def test_batches_in_flight_pass_is_skipped_when_a_step_holds_a_collective():
+    """The crash fixed in 86a7de4 (`--workload stress --gpus 2`): the extra three-batches-in-flight pass drives the steps
+    from three host threads; with an all-gather inside the step the ranks' collectives mis-pair.  The decision is one
+    function: never with a collective in the step on several ranks, never for strong-scaling steps."""
+    bench = _load_bench()
+    plain = types.SimpleNamespace()
+    coll = types.SimpleNamespace(collective_in_step=True)
+    strong = types.SimpleNamespace(collective_in_step=True, scaling="strong")
+    assert bench.overlap_probe_allowed(1, 8, False, 1, plain)
+    assert bench.overlap_probe_allowed(1, 8, False, 8, plain)          # chair / table: no collective in the step
+    assert bench.overlap_probe_allowed(1, 8, False, 1, coll)           # one rank: nothing to mis-pair
+    assert not bench.overlap_probe_allowed(1, 8, False, 2, coll)       # stress on 2 ranks
+    assert not bench.overlap_probe_allowed(1, 8, False, 1, strong) and not bench.overlap_probe_allowed(1, 8, False, 4, strong)
+    assert not bench.overlap_probe_allowed(3, 8, False, 1, plain) and not bench.overlap_probe_allowed(1, 1, False, 1, plain)
+    assert not bench.overlap_probe_allowed(1, 8, True, 1, plain)
+    assert bench.StressWorkload.collective_in_step and bench.StrongEvalWorkload.collective_in_step
+    assert not getattr(bench.RegistrationWorkload, "collective_in_step", False)

@@ -155,3 +155,72 @@ def test_sharding_exchange_runs_on_rccl(gpu):
         assert t.tolist() == [1.5, 2.5]
     finally:
         dist.destroy_process_group()
+
+
+def _sharded_eval_inputs():
+    from corsair_amd import synth
+
+    C, Q, n = 12, 10, 3000
+    catalog = [synth.make_cloud(c, 15000)[:n] for c in range(C)]
+    queries = [synth.apply_pose(synth.make_cloud(q % C, 15000)[15000 - n:], synth.random_pose(q, max_trans=0.0), np.float64)
+               for q in range(Q)]
+    rng = np.random.default_rng(4)
+    table = rng.random((C, C))
+    table = table + table.T
+    np.fill_diagonal(table, 0.0)
+    syms = np.ones(C, np.int32)
+    syms[[1, 4]] = [2, 4]
+    return (catalog, queries, np.arange(Q) % C, table, np.stack([synth.random_pose(q, max_trans=0.0) for q in range(Q)]),
+            np.stack([np.eye(4)] * C), syms)
+
+
+def _sharded_eval_rank(rank, world, port, out_dir):
+    import os
+    import pickle
+
+    import torch.distributed as dist
+
+    from corsair_amd import harness, sharding, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks share the box's one GPU: no RCCL
+    try:
+        sd, emb = synth.make_state_dicts(31)
+        pipe = harness.Pipeline(sd, emb, device=torch.device("cuda:0"),
+                                config=harness.Config(n_points=3000, ransac_max_iter=3000, batch_size=4))
+        res = sharding.run_eval_sharded(pipe, dist, rank, world, *_sharded_eval_inputs(), "chair", True,
+                                        os.path.join(out_dir, "cache"), True)
+        with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
+            pickle.dump((res.stat, res.per_query, res.report), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluation_two_ranks_equals_single_rank_on_the_gpu(gpu, tmp_path):
+    """sharding.run_eval_sharded with the REAL pipeline: two ranks (sharing the one GPU of the test box, exchange over
+    gloo) produce the single-rank harness.run_eval result bit for bit -- descriptors, retrieval statistics, the nine
+    per-query arrays in query order -- and rank 0 writes the result cache once (evaluation.py:334-383,421-441)."""
+    import pickle
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from corsair_amd import cache, harness, synth
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_eval_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sd, emb = synth.make_state_dicts(31)
+    pipe = harness.Pipeline(sd, emb, device=gpu, config=harness.Config(n_points=3000, ransac_max_iter=3000, batch_size=4))
+    want = harness.run_eval(pipe, *_sharded_eval_inputs(), "chair", True, force_gate=True)
+    for r in range(2):
+        with open(tmp_path / f"r{r}.pkl", "rb") as f:
+            stat, per_query, report = pickle.load(f)
+        assert stat == want.stat and report == want.report
+        for k in cache.NAMES:
+            assert np.array_equal(per_query[k], want.per_query[k]), (r, k)
+    loaded = cache.load_results(str(tmp_path / "cache"), "chair", True)
+    assert all(np.array_equal(loaded[k], want.per_query[k]) for k in cache.NAMES)
