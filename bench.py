@@ -91,6 +91,8 @@ def parse():
                     help="skip the extra pass that times the dominant kernel without concurrent work")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="chair, 1 GPU: skip the short table (configs[2]) and stress (configs[4]) legs reported as `workloads`")
+    ap.add_argument("--sequential-value", action="store_true",
+                    help="report the one-batch-at-a-time pass as `value` even when the three-batches-in-flight pass ran")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra pass with three batches in flight reported as `batches_in_flight`")
     return ap.parse_args()
@@ -985,16 +987,22 @@ def main():
     if ctx.rank == 0:
         strong = getattr(wl, "scaling", "weak") == "strong"
         total_units = args.steps * wl.units_per_step * (1 if strong else ctx.world)
-        cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": depth})
+        # `value`: the K steps with three batches in flight (three host threads x three HIP streams; identical results
+        # checked) when that pass ran -- VERDICT r3 #5: the embed of step i+1 under the RANSAC of step i is real
+        # throughput --, else the sequential pass.  `sequential` always carries the one-batch-at-a-time figures, and
+        # `roofline` is measured over THAT pass (in the pipelined one a launch's event time includes its neighbours).
+        piped = overlap is not None and overlap[1] and not args.sequential_value
+        head_elapsed = overlap[0] if piped else elapsed
+        cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": 3 if piped else depth})
         out = {
             "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD %s"
                       % ("chair" if args.workload == "stress" else args.workload),
-            "value": total_units / elapsed,
+            "value": total_units / head_elapsed,
             "unit": "queries/s",
             "n_gpus": ctx.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head_elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -1016,13 +1024,17 @@ def main():
                            "rank_elapsed_s": [round(float(v), 4) for v in own],
                            "rank_time_max_over_min": float(own.max() / max(own.min(), 1e-9))}
         wl.extras(out)
+        out["sequential"] = {"value": total_units / elapsed, "unit": "queries/s", "ms_per_step": elapsed / args.steps * 1e3,
+                             "note": "the same K steps one batch at a time (the pass `roofline`, `roofline_by_kernel` and "
+                                     "`kernel_ms` are measured over: their launches share the GPU only with their own step)"}
+        out["roofline"]["pass"] = "sequential"
         if overlap:
             out["batches_in_flight"] = {
                 "depth": 3, "value": total_units / overlap[0], "unit": "queries/s",
                 "ms_per_step": overlap[0] / args.steps * 1e3, "identical_results": bool(overlap[1]),
-                "note": "same K batches again with three host threads x three HIP streams (python bench.py --pipeline 3); "
-                        "not the contract number (the live per-launch times of `roofline` would include the "
-                        "neighbours' kernels)"}
+                "is_headline": bool(piped),
+                "note": "the same K batches with three host threads x three HIP streams (the library's scratch cache is per "
+                        "thread and stream-ordered); results compared with the sequential pass"}
         if ctx.world == 1 and args.workload == "chair" and not strong and not args.no_extra_workloads:
             # configs[2] and configs[4] under the same clock as the headline (short legs, same measurement).  BEFORE the
             # CPU baseline: after it the table leg measured 429 instead of 568 queries/s on the same box (the oracle's

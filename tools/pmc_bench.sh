@@ -3,5 +3,5 @@
 out=$1; ctr=$2
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$root/$out" -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-probe --no-solo-probe > "$root/$out.log" 2>&1
+rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$root/$out" -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-probe --no-solo-probe --no-extra-workloads > "$root/$out.log" 2>&1
 cd "$root" && python3 tools/pmc_summary.py "$out"

@@ -81,7 +81,7 @@ for k in sorted(set(fa) | set(sa)):
 rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
 with open(f"{out}/pmc_table.txt", "w") as f:
     f.write("# tools/pmc_collect.sh: rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ set} -- python3 bench.py "
-            + " ".join(sys.argv[2:]) + " --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-probe --no-solo-probe\n")
+            + " ".join(sys.argv[2:]) + " --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-probe --no-solo-probe --no-extra-workloads\n")
     f.write("# hbm = (2x for 16-B/lane streaming kernels) FETCH_SIZE + WRITE_SIZE per launch; mfma_busy / valu_active = share of SIMD cycles;\n"
             "# wait_any / wait_inst = share of wave cycles parked (waitcnt, barrier) / stalled at issue\n")
     f.write(f"{'kernel':46s} {'launches':>8s} {'hbm MB/launch':>14s} {'mfma_busy':>9s} {'valu':>6s} {'wait_any':>8s} {'wait_inst':>9s} {'kcycles':>8s}\n")
@@ -117,7 +117,7 @@ if dom:
           "csrc_sha": csrc_sha(),
           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (three separate passes, tools/pmc_collect.sh) on "
                     "`python bench.py " + " ".join(sys.argv[2:]) + " --steps 3 --warmup 1 --no-cpu-baseline "
-                    "--no-overlap-probe --no-solo-probe`"}
+                    "--no-overlap-probe --no-solo-probe --no-extra-workloads`"}
     json.dump(js, open(f"{out}/pmc.json", "w"), indent=1)
     print(json.dumps(js))
 print(open(f"{out}/pmc_table.txt").read())

@@ -5,7 +5,7 @@ out=$1; shift
 root=$(pwd)
 python3 bench.py "$@" > "$out"_line.json 2> "$out"_line.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out" -- python3 "$root/bench.py" "$@" --no-cpu-baseline --no-overlap-probe --no-solo-probe > "$root/$out"_profiled.json 2> "$root/$out"_profiled.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out" -- python3 "$root/bench.py" "$@" --no-cpu-baseline --no-overlap-probe --no-solo-probe --no-extra-workloads > "$root/$out"_profiled.json 2> "$root/$out"_profiled.err || exit 1
 cd "$root"
 python3 tools/kernel_stats.py "$out" 30
 python3 tools/gap_report.py "$out" 0.5
