@@ -114,6 +114,15 @@ def visible_device_count():
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
             if int(props.get("simd_count", "0")) > 0:      # CPU nodes have no SIMDs
                 n += 1
+        # a container may SEE the host's whole topology but be allowed to open only some render nodes:
+        # count the devices this process can actually open
+        try:
+            nodes = [f for f in os.listdir("/dev/dri") if f.startswith("renderD")]
+            usable = sum(os.access(os.path.join("/dev/dri", f), os.R_OK | os.W_OK) for f in nodes)
+            if nodes and usable < n:
+                n = usable
+        except OSError:
+            pass
         return n
     except OSError:
         import torch
@@ -150,6 +159,33 @@ def maybe_self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+class GroupDist:
+    """The handful of torch.distributed calls the sharded path makes, bound to ONE process group (None = the default
+    group): corsair_amd.sharding takes any object with these methods."""
+
+    def __init__(self, dist, group):
+        self._d, self._g = dist, group
+        self.ReduceOp = dist.ReduceOp
+
+    def get_backend(self):
+        return self._d.get_backend(self._g)
+
+    def all_gather(self, out, t):
+        return self._d.all_gather(out, t, group=self._g)
+
+    def all_gather_into_tensor(self, out, t):
+        return self._d.all_gather_into_tensor(out, t, group=self._g)
+
+    def all_reduce(self, t, op=None):
+        return self._d.all_reduce(t, op=self._d.ReduceOp.SUM if op is None else op, group=self._g)
+
+    def barrier(self):
+        return self._d.barrier(group=self._g)
+
+    def destroy_process_group(self):
+        return self._d.destroy_process_group()
+
+
 class Ctx:
     """What a workload needs from the process: rank layout, device, the one dist handle, logging."""
 
@@ -173,40 +209,36 @@ class Ctx:
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
+            from datetime import timedelta
 
+            # The DEFAULT group is always gloo (control plane: it comes up wherever TCP does); RCCL is a second group
+            # the data collectives run on.  Whether RCCL is usable is agreed on over gloo BEFORE anything depends on it
+            # (no second TCPStore on MASTER_PORT + 1, no rank left blocking in an RCCL collective while its
+            # peer has already given up -- the RCCL group's own timeout is one minute).
+            dist.init_process_group("gloo")
+            group, err = None, None
             if self.backend == "nccl":
-                # RCCL failing to come up is an ERROR (exit non-zero with the reason): a scaling run that quietly
-                # measured gloo would be worse than none.  --allow-gloo turns it into a gloo run, and then every
-                # rank takes the same decision: the verdicts are exchanged through torchrun's store first.
-                err = None
                 try:
-                    dist.init_process_group("nccl", device_id=self.dev)
+                    group = dist.new_group(backend="nccl", timeout=timedelta(seconds=60), device_id=self.dev)
                     probe = torch.ones(1, device=self.dev)
-                    dist.all_reduce(probe)              # first collective: communicator really comes up
+                    dist.all_reduce(probe, group=group)     # first collective: the communicator really comes up
                     torch.cuda.synchronize()
-                except Exception as e:
+                except Exception as e:                      # noqa: BLE001 (reported below, with the rank)
                     err = e
-                if err is not None and not args.allow_gloo:
-                    sys.stderr.write("[bench] rank %d: RCCL init failed: %s\n[bench] refusing to fall back to gloo "
-                                     "silently (pass --allow-gloo to measure over gloo)\n" % (self.rank, err))
-                    sys.exit(3)
-                if args.allow_gloo:
-                    from datetime import timedelta
-
-                    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, self.world,
-                                          self.rank == 0, timeout=timedelta(seconds=120))
-                    store.set("rccl_ok_%d" % self.rank, "0" if err is not None else "1")
-                    all_ok = all(store.get("rccl_ok_%d" % r) == b"1" for r in range(self.world))
-                    if not all_ok:
-                        sys.stderr.write("[bench] rank %d: RCCL unusable on at least one rank (%s); --allow-gloo: "
-                                         "all ranks switch to gloo\n" % (self.rank, err))
-                        if dist.is_initialized():
-                            dist.destroy_process_group()
-                        self.backend = "gloo"
-                        dist.init_process_group("gloo")
-            else:
-                dist.init_process_group(self.backend)
-            self.dist = dist
+                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # gloo: every rank learns whether ALL ranks have RCCL
+                if int(ok) == 0:
+                    # RCCL failing to come up is an ERROR (exit non-zero with the reason): a scaling run that quietly
+                    # measured gloo would be worse than none.  --allow-gloo turns it into a gloo run on ALL ranks.
+                    if not args.allow_gloo:
+                        sys.stderr.write("[bench] rank %d: RCCL unusable on at least one rank (here: %s)\n[bench] refusing to "
+                                         "fall back to gloo silently (pass --allow-gloo to measure over gloo)\n"
+                                         % (self.rank, err))
+                        sys.exit(3)
+                    sys.stderr.write("[bench] rank %d: RCCL unusable on at least one rank (here: %s); --allow-gloo: all "
+                                     "ranks use gloo\n" % (self.rank, err))
+                    self.backend, group = "gloo", None
+            self.dist = GroupDist(dist, group)
 
     def log(self, msg):
         if self.rank == 0:

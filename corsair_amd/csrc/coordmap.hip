@@ -396,31 +396,47 @@ static int ensure_segments_many(cs_coordmap* const* maps, int n, hipStream_t s) 
   if (todo.empty()) return CS_OK;
   const size_t k = todo.size();
   std::vector<int32_t> last_b(k, -1);
-  for (size_t i = 0; i < k; ++i)
-    CS_HIP_CHECK(download_async(&last_b[i], todo[i]->d_coords + 4 * (todo[i]->n - 1), sizeof(int32_t), s));
-  CS_HIP_CHECK(download_sync(s));
-  PoolBuf<int> flags(2 * k);
-  if (!flags.p) return CS_OK;
-  CS_HIP_CHECK(hipMemsetAsync(flags.p, 0, 2 * k * sizeof(int), s));
   std::vector<int32_t*> seg(k, nullptr);
   std::vector<int> h_flags(2 * k, 0);
-  for (size_t i = 0; i < k; ++i) {
+  // every HIP error is COLLECTED (no return in the middle of the loops): on failure the blocks allocated so far go
+  // back to the pool and the maps return to "not computed" (seg_state 0), so a later call can try again
+  hipError_t e = hipSuccess;
+  auto keep = [&e](hipError_t r) {
+    if (e == hipSuccess && r != hipSuccess) e = r;
+  };
+  for (size_t i = 0; i < k && e == hipSuccess; ++i)
+    keep(download_async(&last_b[i], todo[i]->d_coords + 4 * (todo[i]->n - 1), sizeof(int32_t), s));
+  if (e == hipSuccess) keep(download_sync(s));
+  PoolBuf<int> flags(2 * k);
+  if (e == hipSuccess && !flags.p) e = hipErrorOutOfMemory;
+  if (e == hipSuccess) keep(hipMemsetAsync(flags.p, 0, 2 * k * sizeof(int), s));
+  for (size_t i = 0; i < k && e == hipSuccess; ++i) {
     cs_coordmap* m = todo[i];
-    if (last_b[i] < 0 || last_b[i] >= 65536) continue;
+    if (last_b[i] < 0 || last_b[i] >= 65536) continue;   // stays -1: the global-table path serves this map
     const int nb = last_b[i] + 1;
     seg[i] = (int32_t*)pool_alloc((size_t)(nb + 1) * sizeof(int32_t));
-    if (!seg[i]) continue;
-    CS_HIP_CHECK(hipMemsetAsync(seg[i], 0, (size_t)(nb + 1) * sizeof(int32_t), s));
+    if (!seg[i]) {
+      e = hipErrorOutOfMemory;
+      break;
+    }
+    keep(hipMemsetAsync(seg[i], 0, (size_t)(nb + 1) * sizeof(int32_t), s));
+    if (e != hipSuccess) break;
     hipLaunchKernelGGL(k_segments, dim3((unsigned)ceil_div(m->n, 256)), dim3(256), 0, s, m->d_coords, m->n, nb, seg[i],
                        flags.p + 2 * i);
     hipLaunchKernelGGL(k_segment_max, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, s, seg[i], nb, flags.p + 2 * i);
+    keep(hipGetLastError());
   }
-  hipError_t e = download_async(h_flags.data(), flags.p, 2 * k * sizeof(int), s);
-  if (e == hipSuccess) e = download_sync(s);
+  if (e == hipSuccess) keep(download_async(h_flags.data(), flags.p, 2 * k * sizeof(int), s));
+  if (e == hipSuccess) keep(download_sync(s));
   for (size_t i = 0; i < k; ++i) {
     cs_coordmap* m = todo[i];
+    if (e != hipSuccess) {
+      pool_free(seg[i]);          // (nullptr is fine)
+      m->seg_state = 0;           // not computed: nothing about this map was learnt
+      continue;
+    }
     if (!seg[i]) continue;
-    if (e != hipSuccess || h_flags[2 * i]) {   // (not grouped by sample: global path)
+    if (h_flags[2 * i]) {         // not grouped by sample: global path, seg_state stays -1
       pool_free(seg[i]);
       continue;
     }
@@ -948,7 +964,7 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_small),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          SORT_SMALL_MAX * (int)sizeof(unsigned long long));
-      e2 = attr;
+      if (e2 == hipSuccess) e2 = attr;   // (keeps an earlier error, e.g. of the cnt_ready record)
       if (e2 == hipSuccess)
         hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), (size_t)npow2 * sizeof(unsigned long long), s, key.p, (int)n,
                            npow2, key_sorted.p, km->d_rowlist);

@@ -996,8 +996,7 @@ __global__ void k_topk_init(unsigned long long* carry_d, int* carry_i, int64_t n
 }
 // squared: write the squared distances the ranking was made on (cs_l2_topk_sq: shard merges compare exactly
 // what the kernels compared; two different squares can share one rounded square root)
-static thread_local int t_topk_squared = 0;
-static thread_local const ::cs_topk_catalog* t_topk_catalog = nullptr;   // set by cs_l2_topk_catalog around cs_l2_topk
+// (an explicit argument of every internal top-k function: no side channel between the entry points)
 __global__ void k_topk_finish(const unsigned long long* carry_d, const int* carry_i, int64_t n,
                               int64_t* idx, double* dist, int squared) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1847,7 +1846,7 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
 
 // f64 matrix-pipe shortlist + canonical re-score (k <= TKM_KK - 2)
 static int topk_f64_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
-                              int64_t* d_idx, double* d_dist, hipStream_t s) {
+                              int64_t* d_idx, double* d_dist, hipStream_t s, int squared) {
   int nsplit = (int)(2048 / ceil_div(nq, TKM_QT));
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 64) nsplit = 64;
@@ -1866,7 +1865,7 @@ static int topk_f64_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand,
                      k, cd.p, ci.p);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
-                     ci.p, nq * k, d_idx, d_dist, t_topk_squared);
+                     ci.p, nq * k, d_idx, d_dist, squared);
   CS_LAUNCH_CHECK();
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }
@@ -1899,7 +1898,8 @@ static int tkf_prepare_catalog(const float* d_x, int64_t nx, int d, _Float16* xi
 }
 
 static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
-                              int64_t* d_idx, double* d_dist, hipStream_t s, const TkfCatalog* prepared = nullptr) {
+                              int64_t* d_idx, double* d_dist, hipStream_t s, int squared,
+                              const TkfCatalog* prepared = nullptr) {
   const int dch = d / 16;
   const int pitch_h = tkf_pitch(d);
   const int64_t qtiles = ceil_div(nq, TKF_QT);
@@ -1955,7 +1955,7 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_tkf_verify, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, cd.p, k, nq, tau.p,
                      nlane, qn.p, cat.xmax, d, terms, flagged.p, n_flagged);
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p, ci.p,
-                     nq * k, d_idx, d_dist, t_topk_squared);
+                     nq * k, d_idx, d_dist, squared);
   CS_LAUNCH_CHECK();
   int h_flagged = 0;
   CS_HIP_CHECK(download_async(&h_flagged, n_flagged, sizeof(int), s));
@@ -1970,7 +1970,7 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
     CS_REQUIRE(qf.p && fi.p && fd.p, CS_ERR_HIP, "cs_l2_topk: scratch allocation failed");
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div(nf * d, 256)), dim3(256), 0, s, d_q, d, flagged.p,
                        nf, qf.p);
-    rc = topk_f64_shortlist(qf.p, nf, d_x, nx, d, k, fi.p, fd.p, s);
+    rc = topk_f64_shortlist(qf.p, nf, d_x, nx, d, k, fi.p, fd.p, s, squared);
     if (rc) return rc;
     hipLaunchKernelGGL(k_scatter_topk, dim3((unsigned)ceil_div(nf * k, 256)), dim3(256), 0, s, fi.p, fd.p, k,
                        flagged.p, nf, d_idx, d_dist);
@@ -1990,6 +1990,7 @@ struct cs_topk_catalog {
   _Float16* ximg = nullptr;
   double* xn = nullptr;
   unsigned* xmax = nullptr;
+  hipEvent_t ready = nullptr;   // recorded behind the kernels that make ximg / xn / xmax
 };
 
 int cs_topk_catalog_create(const float* d_x, int64_t nx, int d, void* stream, cs_topk_catalog** out) {
@@ -2009,6 +2010,11 @@ int cs_topk_catalog_create(const float* d_x, int64_t nx, int d, void* stream, cs
     c->xn = (double*)pool_alloc((size_t)nx * sizeof(double));
     c->xmax = (unsigned*)pool_alloc(sizeof(unsigned));
     int rc = (c->ximg && c->xn && c->xmax) ? tkf_prepare_catalog(d_x, nx, d, c->ximg, c->xn, c->xmax, s) : CS_ERR_HIP;
+    if (rc == CS_OK && (hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+                        hipEventRecord(c->ready, s) != hipSuccess)) {
+      set_error("cs_topk_catalog_create: could not record the ready event");
+      rc = CS_ERR_HIP;
+    }
     if (rc) {
       if (rc == CS_ERR_HIP && !(c->ximg && c->xn && c->xmax)) set_error("cs_topk_catalog_create: allocation failed");
       cs_topk_catalog_free(c);
@@ -2024,18 +2030,19 @@ void cs_topk_catalog_free(cs_topk_catalog* c) {
   pool_free(c->ximg);
   pool_free(c->xn);
   pool_free(c->xmax);
+  if (c->ready) (void)hipEventDestroy(c->ready);
   delete c;
 }
+
+static int l2_topk_impl(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k, int64_t* d_idx,
+                        double* d_dist, void* stream, const cs_topk_catalog* cat, int squared);
 
 int cs_l2_topk_catalog(const float* d_q, int64_t nq, const cs_topk_catalog* cat, int k, int64_t* d_idx, double* d_dist,
                        int squared, void* stream) {
   CS_REQUIRE(cat, CS_ERR_INVALID, "cs_l2_topk_catalog: NULL catalog");
-  t_topk_catalog = cat;
-  t_topk_squared = squared ? 1 : 0;
-  const int rc = cs_l2_topk(d_q, nq, cat->d_x, cat->nx, cat->d, k, d_idx, d_dist, stream);
-  t_topk_squared = 0;
-  t_topk_catalog = nullptr;
-  return rc;
+  // what the handle holds was made on the creating call's stream: every user waits for it in stream order
+  if (cat->ready) CS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, cat->ready, 0));
+  return l2_topk_impl(d_q, nq, cat->d_x, cat->nx, cat->d, k, d_idx, d_dist, stream, cat, squared ? 1 : 0);
 }
 
 void cs_l2_topk_stats(uint64_t out[2], int reset) {
@@ -2047,14 +2054,16 @@ void cs_l2_topk_stats(uint64_t out[2], int reset) {
 
 int cs_l2_topk_sq(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k, int64_t* d_idx,
                   double* d_dist2, void* stream) {
-  t_topk_squared = 1;
-  const int rc = cs_l2_topk(d_q, nq, d_x, nx, d, k, d_idx, d_dist2, stream);
-  t_topk_squared = 0;
-  return rc;
+  return l2_topk_impl(d_q, nq, d_x, nx, d, k, d_idx, d_dist2, stream, nullptr, 1);
 }
 
 int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k,
                int64_t* d_idx, double* d_dist, void* stream) {
+  return l2_topk_impl(d_q, nq, d_x, nx, d, k, d_idx, d_dist, stream, nullptr, 0);
+}
+
+static int l2_topk_impl(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d, int k, int64_t* d_idx,
+                        double* d_dist, void* stream, const cs_topk_catalog* cat, int squared) {
   CS_REQUIRE(d_q && d_x && d_idx, CS_ERR_INVALID, "cs_l2_topk: NULL argument");
   CS_REQUIRE(d >= 1 && k >= 1 && k <= 1024 && k <= nx, CS_ERR_INVALID,
              "cs_l2_topk: need 1 <= k <= min(1024, nx) (k %d, nx %lld)", k, (long long)nx);
@@ -2073,16 +2082,15 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
   const bool want64 = force ? (force[0] == '1' || force[0] == '6') : big;
   if (want16 && f16_shape) {
     TkfCatalog pre;
-    const cs_topk_catalog* c = t_topk_catalog;
-    const bool have = c && c->ximg && c->d_x == d_x && c->nx == nx && c->d == d;
+    const bool have = cat && cat->ximg;   // made for exactly (d_x, nx, d): the handle supplies all three
     if (have) {
-      pre.ximg = c->ximg;
-      pre.xn = c->xn;
-      pre.xmax = c->xmax;
+      pre.ximg = cat->ximg;
+      pre.xn = cat->xn;
+      pre.xmax = cat->xmax;
     }
-    return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s, have ? &pre : nullptr);
+    return topk_f16_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s, squared, have ? &pre : nullptr);
   }
-  if (want64 && k <= TKM_KK - 2) return topk_f64_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s);
+  if (want64 && k <= TKM_KK - 2) return topk_f64_shortlist(d_q, nq, d_x, nx, d, k, d_idx, d_dist, s, squared);
   // slab of catalog rows so that the f64 distance slab stays <= 1 GiB
   int64_t slab = (1LL << 27) / (nq > 0 ? nq : 1);
   if (slab < DM_CT) slab = DM_CT;
@@ -2101,7 +2109,7 @@ int cs_l2_topk(const float* d_q, int64_t nq, const float* d_x, int64_t nx, int d
                        ci.p);
   }
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, cd.p,
-                     ci.p, nq * k, d_idx, d_dist, t_topk_squared);
+                     ci.p, nq * k, d_idx, d_dist, squared);
   CS_LAUNCH_CHECK();
   return CS_OK;  // scratch goes back to this thread's stream-ordered cache; outputs are valid in stream order
 }

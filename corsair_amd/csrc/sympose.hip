@@ -79,7 +79,11 @@ __global__ __launch_bounds__(256) void k_corr_assemble(const float* __restrict__
     const int64_t i = e / k;
     const int nb = (int)(e - i * k);
     const int64_t q = rows ? rows[d.q_first + i] : d.q_first + i;
-    const int64_t t = d.t_first + nn[(d.n_first + i) * k + nb];
+    // a missing neighbour (-1: fewer than k targets) never becomes an address: the callers reject such
+    // configurations (registration.py raises for the vanilla list, cs_cfg_bad drops part configurations); should
+    // one get here anyway it reads the cloud's first row instead of the bytes in front of the buffer
+    const int32_t nbv = nn[(d.n_first + i) * k + nb];
+    const int64_t t = d.t_first + (nbv < 0 ? 0 : nbv);
     const int64_t o = (d.out_first * k + e) * 3;
     src[o] = xyz0[q * 3];
     src[o + 1] = xyz0[q * 3 + 1];

@@ -160,6 +160,13 @@ def sym_pose_batch(baseF, xyz0, off0, posF, xyz1, off1, pos_syms, k_nn=5, max_co
     k = k_nn
 
     # ---- 1. vanilla correspondences (find_kcorr, utils/eval_pose.py:48-79) -----------------
+    # A CAD cloud with fewer than k voxels has no k-th neighbour: SciPy's KD-tree returns the out-of-range index n
+    # there and the reference's fancy indexing raises IndexError (utils/eval_pose.py:66-72).  Same here, before any
+    # launch: the neighbour lists would hold -1 (k_corr_assemble must never read through one).
+    short = [p for p in range(P) if n0[p] > 0 and n1[p] < k]
+    if short:
+        raise IndexError("sym_pose_batch: CAD cloud of pair %d has %d voxels, fewer than k_nn = %d (the reference's "
+                         "find_kcorr fails on such a pair too)" % (short[0], n1[short[0]], k))
     nn = B.knn_feat(baseF, off0, posF, off1, k)                     # [N0, k] local CAD rows
     # correspondence lists straight from the neighbour lists (one launch; rounds 1-2 built index tensors with
     # repeat_interleave / arange / gathers): pair p = query rows off0[p]:off0[p+1] against the CAD cloud at off1[p]

@@ -84,6 +84,28 @@ def test_empty_and_tiny_inputs(gpu, oracle_native):
     assert torch.isnan(cd).all()
 
 
+def test_cad_cloud_with_fewer_voxels_than_k_is_refused_like_find_kcorr(gpu):
+    """A CAD cloud with fewer than k voxels has no k-th neighbour: the reference's find_kcorr indexes with SciPy's
+    out-of-range sentinel and raises IndexError (utils/eval_pose.py:66-72).  sym_pose_batch raises the same error before
+    any launch (the vanilla list must never be assembled through a -1 entry), and cs_corr_assemble itself
+    never turns a -1 into an address."""
+    from corsair_amd import backend as B, registration as R
+
+    rng = np.random.default_rng(0)
+    F0 = torch.from_numpy(rng.standard_normal((40, 16)).astype(np.float32)).to(gpu)
+    X0 = torch.from_numpy(rng.uniform(-1, 1, (40, 3)).astype(np.float32)).to(gpu)
+    F1 = torch.from_numpy(rng.standard_normal((3, 16)).astype(np.float32)).to(gpu)
+    X1 = torch.from_numpy(rng.uniform(-1, 1, (3, 3)).astype(np.float32)).to(gpu)
+    with pytest.raises(IndexError, match="fewer than k_nn"):
+        R.sym_pose_batch(F0, X0, [0, 40], F1, X1, [0, 3], [1], 5, 0.2, 0, None, 100, 500, 0.999, True, False)
+    nn = B.knn_feat(F0, [0, 40], F1, [0, 3], 5)
+    assert (nn.cpu().numpy()[:, 3:] == -1).all()
+    desc = np.asarray([[0, 0, 0, 40, 0]], dtype=np.int64)
+    src, tgt = B.corr_assemble(X0, X1, None, nn, desc, 40, 40)
+    tgt = tgt.cpu().numpy().reshape(40, 5, 3)
+    assert np.array_equal(tgt[:, 3], np.tile(X1[0].cpu().numpy(), (40, 1)))      # the cloud's first row, not stray memory
+
+
 def test_ragged_batch_forward_row_order(gpu):
     """Batch of clouds with very different sizes: per-sample row segments stay in input order."""
     from corsair_amd import engine, synth

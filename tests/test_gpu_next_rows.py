@@ -157,6 +157,43 @@ def test_sharding_exchange_runs_on_rccl(gpu):
         dist.destroy_process_group()
 
 
+def test_bench_group_handle_runs_the_exchange_on_an_rccl_subgroup(gpu):
+    """bench.py's process layout: the default group is gloo (control plane), the data collectives run on an
+    RCCL group wrapped in bench.GroupDist -- the object corsair_amd.sharding is handed.  One rank, the one GPU."""
+    import importlib.util
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from corsair_amd import sharding
+    from corsair_amd.harness import EmbeddedSet
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        gd = bench.GroupDist(dist, dist.new_group(backend="nccl", device_id=gpu))
+        assert gd.get_backend() == "nccl" and dist.get_backend() == "gloo"
+        F = torch.arange(5 * 16, dtype=torch.float32, device=gpu).reshape(5, 16)
+        eset = EmbeddedSet(F, F[:, :3].contiguous(), [0, 2, 5], torch.ones((2, 256), device=gpu))
+        (got,) = sharding.all_gather_embedded(gd, eset, 1)
+        assert got.offsets == [0, 2, 5] and torch.equal(got.F, F) and got.F.is_cuda
+        assert sharding.all_gather_counts(gd, [1, 0], [7, 9], 2, 1).tolist() == [9, 7]
+        t = torch.tensor([3.0], device=gpu, dtype=torch.float64)
+        gd.all_reduce(t, op=gd.ReduceOp.MAX)
+        gd.barrier()
+        assert t.item() == 3.0
+    finally:
+        dist.destroy_process_group()
+
+
 def _sharded_eval_inputs():
     from corsair_amd import synth
 
