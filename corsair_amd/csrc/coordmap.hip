@@ -581,6 +581,74 @@ __global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict
 }
 
 // export helpers: element t = k * n_out + o of the k-major view
+// ---- the tiling order of ALL kernel maps of a batch in one pass (round 4) ---------------------------------------------
+// Ten maps of a batch used to mean ten row-key launches, ten device sorts (5 - 20 launches each: hipcub takes a block-sort +
+// merge path for the mid-size maps) and ten table launches: 115 launches per stress batch, 60 per chair batch, bound by
+// launch latency.  Here the keys of all maps go into ONE array -- key = map index << 27 | Gray rank, so one radix sort
+// leaves every map's rows contiguous and ordered -- and one launch writes all sorted tables.  The descriptors travel as a
+// kernel argument (no upload).
+constexpr int ORDER_MAX_MAPS = 16;
+struct OrderMap {
+  const int32_t* nbr;
+  int32_t* nbr_sorted;
+  uint32_t* gmask;
+  int32_t* rowlist;
+  const unsigned long long* d_cnt;
+  unsigned long long* host_cnt;
+  int64_t n_out, base, n_groups;
+  int32_t absent;
+  uint32_t kblk0, tblk0;   // first workgroup of this map in the key / table launch
+};
+struct OrderTab {
+  int n;
+  OrderMap m[ORDER_MAX_MAPS];
+};
+__global__ __launch_bounds__(256) void k_row_keys_all(const OrderTab tab, uint32_t* __restrict__ key,
+                                                      int32_t* __restrict__ row) {
+  int i = 0;
+  while (i + 1 < tab.n && blockIdx.x >= tab.m[i + 1].kblk0) ++i;
+  const OrderMap& mp = tab.m[i];
+  const int64_t o = (int64_t)(blockIdx.x - mp.kblk0) * 256 + threadIdx.x;
+  if (o == 0 && mp.host_cnt) __hip_atomic_store(mp.host_cnt, *mp.d_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (o >= mp.n_out) return;
+  uint32_t m = 0;
+  for (int k = 0; k < 27; ++k) m |= (mp.nbr[o * 27 + k] >= 0 ? 1u : 0u) << k;
+  m ^= m >> 1;   // inverse Gray code (see k_row_keys)
+  m ^= m >> 2;
+  m ^= m >> 4;
+  m ^= m >> 8;
+  m ^= m >> 16;
+  key[mp.base + o] = ((uint32_t)i << 27) | m;
+  row[mp.base + o] = (int32_t)o;
+}
+__global__ __launch_bounds__(256) void k_sorted_tables_all(const OrderTab tab, const uint32_t* __restrict__ key_sorted,
+                                                           const int32_t* __restrict__ row_sorted) {
+  int i = 0;
+  while (i + 1 < tab.n && blockIdx.x >= tab.m[i + 1].tblk0) ++i;
+  const OrderMap& mp = tab.m[i];
+  const int64_t e = (int64_t)(blockIdx.x - mp.tblk0) * 256 + threadIdx.x;
+  const int32_t* rl = row_sorted + mp.base;
+  const uint32_t* ks = key_sorted + mp.base;
+  if (e < mp.n_out * 27) {
+    const int64_t t = e / 27;
+    const int k = (int)(e - t * 27);
+    const int32_t v = mp.nbr[(int64_t)rl[t] * 27 + k];
+    mp.nbr_sorted[e] = v < 0 ? mp.absent : v;
+  }
+  if (e < mp.n_out) mp.rowlist[e] = rl[e];
+  if (e < mp.n_groups) {
+    uint32_t m = 0;
+    for (int r = 0; r < 32; ++r) {
+      const int64_t t = e * 32 + r;
+      if (t < mp.n_out) {
+        const uint32_t rank = ks[t] & 0x7ffffffu;
+        m |= rank ^ (rank >> 1);
+      }
+    }
+    mp.gmask[e] = m;
+  }
+}
+
 __global__ void k_export_flag(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
                               int32_t* flag) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -797,8 +865,12 @@ void cs_coordmap_free(cs_coordmap* m) {
 }  // extern "C"
 
 // one kernel map on stream `s` (the caller has announced its stream to the pool)
+// defer_order: leave the tiling order (row list, sorted table, group masks) and the pair-count hand-over to
+// order_many(), which does them for all maps of a batch at once; *d_cnt_out then receives the device counter
+// (scratch of this call: valid until the caller ends its pool deferral)
 static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int kernel_size, int transposed,
-                              hipStream_t s, cs_kernelmap** km_out) {
+                              hipStream_t s, cs_kernelmap** km_out, bool defer_order = false,
+                              const unsigned long long** d_cnt_out = nullptr) {
   CS_REQUIRE(in && out && km_out, CS_ERR_INVALID, "cs_kernelmap_build: NULL argument");
   *km_out = nullptr;
   CS_REQUIRE(kernel_size == 3 || kernel_size == 1, CS_ERR_UNSUPPORTED,
@@ -923,7 +995,7 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
       if (!km->h_cnt || hipEventCreateWithFlags(&km->cnt_ready, hipEventDisableTiming) != hipSuccess) {
         e = hipErrorOutOfMemory;
       } else if (km->kvol == 27) {
-        // the row-key kernel below writes the count into the page-locked slot itself (no copy launch)
+        // the row-key kernel (below, or order_many's) writes the count into the page-locked slot itself (no copy launch)
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&cnt_host_dev), km->h_cnt, 0) != hipSuccess)
           cnt_host_dev = nullptr;
       }
@@ -937,6 +1009,11 @@ static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int
     cs_kernelmap_free(km);
     set_error("cs_kernelmap_build: %s", hipGetErrorString(e));
     return CS_ERR_HIP;
+  }
+  if (defer_order && km->kvol == 27 && km->n_out > 0 && cnt_host_dev) {
+    *d_cnt_out = d_cnt;
+    *km_out = km;
+    return CS_OK;
   }
   // tiling order for the convolution kernels: rows sorted by the Gray rank of their presence mask
   if (km->kvol == 27 && km->n_out > 0) {
@@ -1002,6 +1079,62 @@ int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel
   return kernelmap_build_on(in, out, kernel_size, transposed, (hipStream_t)stream, km_out);
 }
 
+// Tiling order of the maps kms[idx[0..m)] (all kvol 27, n_out > 0, built with defer_order) on stream s, which is
+// behind every stream that built them: one key launch, one radix sort, one table launch.
+static int order_many(cs_kernelmap* const* kms, const unsigned long long* const* d_cnts, const int* idx, int m,
+                      hipStream_t s) {
+  if (m == 0) return CS_OK;
+  OrderTab tab;
+  tab.n = m;
+  int64_t total = 0;
+  uint64_t kblk = 0, tblk = 0;
+  for (int j = 0; j < m; ++j) {
+    cs_kernelmap* km = kms[idx[j]];
+    OrderMap& o = tab.m[j];
+    const int64_t n = km->n_out;
+    o.n_out = n;
+    o.base = total;
+    o.n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
+    o.absent = (int32_t)km->n_in;
+    o.nbr = km->d_nbr;
+    km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
+    km->d_nbr_sorted = (int32_t*)pool_alloc((size_t)n * 27 * sizeof(int32_t));
+    km->d_gmask = (uint32_t*)pool_alloc((size_t)o.n_groups * sizeof(uint32_t));
+    CS_REQUIRE(km->d_rowlist && km->d_nbr_sorted && km->d_gmask, CS_ERR_HIP, "cs_kernelmap_build_many: sorted table allocation failed");
+    o.rowlist = km->d_rowlist;
+    o.nbr_sorted = km->d_nbr_sorted;
+    o.gmask = km->d_gmask;
+    o.d_cnt = d_cnts[idx[j]];
+    o.host_cnt = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&o.host_cnt), km->h_cnt, 0) != hipSuccess) o.host_cnt = nullptr;
+    CS_REQUIRE(o.host_cnt, CS_ERR_HIP, "cs_kernelmap_build_many: no device view of the pair-count slot");
+    o.kblk0 = (uint32_t)kblk;
+    o.tblk0 = (uint32_t)tblk;
+    kblk += (uint64_t)ceil_div(n, 256);
+    tblk += (uint64_t)ceil_div(n * 27, 256);
+    total += n;
+  }
+  CS_REQUIRE(total < (1LL << 31) && tblk < (1ULL << 31), CS_ERR_UNSUPPORTED, "cs_kernelmap_build_many: batch too large");
+  int map_bits = 0;
+  while ((1 << map_bits) < m) ++map_bits;
+  PoolBuf<uint32_t> key(total), key_sorted(total);
+  PoolBuf<int32_t> row(total), row_sorted(total);
+  size_t tmp_bytes = 0;
+  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p, row_sorted.p, (int)total, 0,
+                                                  27 + map_bits, s));
+  PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+  CS_REQUIRE(key.p && key_sorted.p && row.p && row_sorted.p && tmp.p, CS_ERR_HIP,
+             "cs_kernelmap_build_many: row order scratch allocation failed");
+  hipLaunchKernelGGL(k_row_keys_all, dim3((unsigned)kblk), dim3(256), 0, s, tab, key.p, row.p);
+  CS_LAUNCH_CHECK();
+  for (int j = 0; j < m; ++j) CS_HIP_CHECK(hipEventRecord(kms[idx[j]]->cnt_ready, s));
+  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, row_sorted.p, (int)total, 0,
+                                                  27 + map_bits, s));
+  hipLaunchKernelGGL(k_sorted_tables_all, dim3((unsigned)tblk), dim3(256), 0, s, tab, key_sorted.p, row_sorted.p);
+  CS_LAUNCH_CHECK();
+  return CS_OK;
+}
+
 // The kernel maps of a batch are independent chains of ~10-20 small dependent launches each (table, row keys, sort,
 // tiling-order tables): enqueued one behind the other they are bound by launch latency, not by the GPU.  Here map i
 // goes to stream i % N (the caller's, and N - 1 of the thread's side streams): every side stream starts behind the caller's
@@ -1057,9 +1190,14 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
     CS_HIP_CHECK(hipEventCreateWithFlags(&join[k].e, hipEventDisableTiming));
     CS_HIP_CHECK(hipStreamWaitEvent(st[k], fork.e, 0));
   }
+  // CS_KMAP_ORDER_MANY=0: every map orders its own rows on its own stream (the round-3 path)
+  static const bool order_all = !(getenv("CS_KMAP_ORDER_MANY") && getenv("CS_KMAP_ORDER_MANY")[0] == '0');
+  const bool defer = order_all && n <= ORDER_MAX_MAPS;
+  std::vector<const unsigned long long*> d_cnts(n, nullptr);
   pool_defer_begin();
   int rc = CS_OK;
-  for (int i = 0; i < n && rc == CS_OK; ++i) rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], st[i % ns], &km_out[i]);
+  for (int i = 0; i < n && rc == CS_OK; ++i)
+    rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], st[i % ns], &km_out[i], defer, &d_cnts[i]);
   // join (also on the error path: the side streams may hold work that reads scratch of this call)
   hipError_t je = hipSuccess;
   for (int k = 1; k < ns; ++k) {
@@ -1069,6 +1207,15 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
       (void)hipStreamSynchronize(st[k]);
       je = e1;
     }
+  }
+  // the tiling order of all deferred maps in one pass on the caller's stream, behind the join and BEFORE the deferred
+  // scratch (the maps' device counters) goes back to the pool
+  if (rc == CS_OK && je == hipSuccess && defer) {
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i)
+      if (km_out[i] && d_cnts[i]) idx.push_back(i);
+    ProfScope prof("kmap", s);
+    rc = order_many(km_out, d_cnts.data(), idx.data(), (int)idx.size(), s);
   }
   if (rc != CS_OK || je != hipSuccess) {
     for (int i = 0; i < n; ++i) {
