@@ -545,7 +545,9 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
 // ------------------------------------------------------------------------------------------------
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int PF_K = 16;        // halfs per hypothesis row (32 B): a_hi, used by both MFMAs
-constexpr int PF_PITCH = 40;    // halfs per pair row (80 B = 5 slots of 16 B: conflict-free ds_read_b128)
+constexpr int PF_PITCH = 40;    // halfs per pair row, K = 32 form (80 B = 5 slots of 16 B: conflict-free ds_read_b128)
+constexpr int PF_PITCH1 = 24;   // halfs per pair row, K = 16 form (48 B = 3 slots: rows 0..15 start in 16 different slots of 4 banks)
+__host__ __device__ constexpr int pf_pitch(int nm) { return nm == 2 ? PF_PITCH : PF_PITCH1; }
 constexpr int PF_ROWS = 192;    // pairs per LDS stage (6 MFMA row tiles)
 constexpr int PF_NG = 2;        // 32-hypothesis groups per wave (LDS fragments are reused NG times)
 constexpr int PF_HYP = 4 * 32 * PF_NG;  // hypotheses per workgroup
@@ -567,6 +569,10 @@ __host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_
 // is +60000 (never counted).  stat[p] = {largest point norm, max |b_k| (k = 0..15)} of problem p as
 // float bit patterns (non-negative floats order like their bits), rounded up.
 // grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
+// NM = 2: rows [bh | bl | pad] of the K = 32 form.  NM = 1 (round 4): rows [bh | pad] of the K = 16 form -- the matrix pipe
+// then evaluates a_hi . b_hi only, and what it drops, a_hi . b_lo, is bounded PER PAIR and taken out of the pair's constant
+// term b_0 (a_0 = 1 exactly) by k_ransac_pack16_b0 below, so the sign test stays an upper bound (see there).
+template <int NM>
 __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restrict__ probs,
                                                        const int64_t* __restrict__ off16,
                                                        const float* __restrict__ src,
@@ -580,6 +586,7 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 #pragma unroll
   for (int k = 0; k < PF_STAT; ++k) mx[k] = 0.f;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < mpad; j += gridDim.x * blockDim.x) {
+    constexpr int NV = pf_pitch(NM) / 8;   // 16-B pieces per row
     union {
       _Float16 h[PF_PITCH];
       uint4 v[5];
@@ -611,15 +618,15 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
           mx[1 + k] = fmaxf(mx[1 + k], __double2float_ru(fabs(b[k])));
         }
         row.h[k] = hi;
-        row.h[16 + k] = lo;
+        if (NM == 2) row.h[16 + k] = lo;
       }
       mx[0] = fmaxf(mx[0], mag);
     } else {
       row.h[0] = (_Float16)60000.0f;  // pairs with a_0 = 1
     }
-    uint4* dst = reinterpret_cast<uint4*>(B16 + (off16[blockIdx.y] + j) * PF_PITCH);
+    uint4* dst = reinterpret_cast<uint4*>(B16 + (off16[blockIdx.y] + j) * pf_pitch(NM));
 #pragma unroll
-    for (int k = 0; k < 5; ++k) dst[k] = row.v[k];
+    for (int k = 0; k < NV; ++k) dst[k] = row.v[k];
   }
 #pragma unroll
   for (int k = 0; k < PF_STAT; ++k) {
@@ -632,6 +639,57 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
     const int k = threadIdx.x;
     const float m = fmaxf(fmaxf(red[0][k], red[1][k]), fmaxf(red[2][k], red[3][k]));
     if (m > 0.f) atomicMax(&stat[blockIdx.y * PF_STAT + k], __float_as_uint(m));
+  }
+}
+
+// K = 16 form, second pass over the pairs (needs the problem's smax, which the first pass produces): the constant term of
+// every pair becomes   b_0' = round_down_f16( b_0 - E_p ),   E_p = (1 + 2^-10) sum_{k=1..15} A_k |b_k - hi(b_k)|,
+// with A_k an upper bound of |a_hi_k| over all USABLE hypotheses of the problem:
+//   k = 4..12  (a = -2 R):          |a| <= 2 sqrt(1 + max|E|) <= 2.002   (k_ransac_hyp16 requires max|E| < 1e-3)
+//   k = 1..3, 13..15 (2 R^T t, -2 t): |a| <= 2 |t| sqrt(1 + max|E|) with |t| <= tcap * smax: k_ransac_hyp16 CHECKS that and
+//     marks the other hypotheses unusable (they survive to the exact kernels).  |t| = |c_t - R c_s| can reach 2 smax, but
+//     both centroids are means of ten points of a centred object: on the bench clouds |t| / smax has median 0.2 and
+//     99.99 % of the hypotheses are below 0.8, so tcap = 0.75 (CS_RANSAC_PF_TCAP) costs 1e-4 of them and shrinks E_p 2.7x
+// The constant term is also CENTRED: b_0 - beta with beta = smax^2 (b_0 = |s|^2 + |q|^2 lies in [0, 2 smax^2]); the
+// hypothesis side adds beta to its accumulator input.  f16 is finer near zero: the round-down costs ~6e-5 instead of 2.4e-4.
+// and |a_hi| <= |a| (1 + 2^-11).  Then  sum_k a_hi_k b'_k  <=  sum_k a_hi_k (b_hi_k + b_lo_k)  for every usable hypothesis:
+// the one-MFMA value is never above what the K = 32 form computes exactly, i.e. every pair the K = 32 form counts is
+// counted -- the count stays an UPPER bound (k_ransac_hyp16's eps_h covers the rest as before).  The price is a looser
+// bound: E_p is ~1e-3 for unit-sized objects (2.5 % of thr^2 = 0.04), the rounding of b_0 another ~2.4e-4 on average.
+__global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __restrict__ probs,
+                                                          const int64_t* __restrict__ off16,
+                                                          const float* __restrict__ src, const float* __restrict__ tgt,
+                                                          const unsigned* __restrict__ stat, double tcap,
+                                                          _Float16* __restrict__ B16) {
+  const RansacProb pr = probs[blockIdx.y];
+  const double smax = (double)__uint_as_float(stat[blockIdx.y * PF_STAT]);
+  if (!(smax <= (double)PF_SMAX)) return;   // the problem bypasses the prefilter (every hypothesis unusable)
+  const double beta = smax * smax;
+  const double a_rot = 2.002 * (1.0 + 0x1p-11), a_t = 2.0 * tcap * smax * 1.0005 * (1.0 + 0x1p-11);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pr.m; j += gridDim.x * blockDim.x) {
+    const int64_t i = pr.off + j;
+    const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
+    const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
+    const double b[16] = {ss + qq, sx, sy, sz, qx * sx, qx * sy, qx * sz, qy * sx, qy * sy, qy * sz,
+                          qz * sx, qz * sy, qz * sz, qx, qy, qz};
+    double e_t = 0.0, e_rot = 0.0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const double lo = fabs(b[k] - (double)(_Float16)b[k]);
+      if (k >= 4 && k <= 12) e_rot += lo; else e_t += lo;
+    }
+    const double ep = (1.0 + 0x1p-10) * (a_rot * e_rot + a_t * e_t);
+    // round toward -inf into f16: RNE first, one ulp down when that landed above
+    const double v = (b[0] - beta) - ep - 0x1p-40 * (fabs(b[0]) + beta + ep);   // (the f64 roundings of the terms themselves)
+    _Float16 h = (_Float16)v;
+    if ((double)h > v) {
+      unsigned short u = __builtin_bit_cast(unsigned short, h);
+      // next representable value below: magnitude down for positive values, up for negative ones (+0 -> -min subnormal)
+      u = (u & 0x8000u) ? (unsigned short)(u + 1) : (u == 0 ? (unsigned short)0x8001u : (unsigned short)(u - 1));
+      h = __builtin_bit_cast(_Float16, u);
+    }
+    B16[(off16[blockIdx.y] + j) * PF_PITCH1] = h;
   }
 }
 
@@ -654,7 +712,7 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
                                const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
                                double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
-                               int32_t* __restrict__ cnt_zero) {
+                               int32_t* __restrict__ cnt_zero, double tcap) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
@@ -693,6 +751,10 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
       dev = fmax(dev, fabs(e));
     }
   bool usable = smax <= (double)PF_SMAX && tn <= 4.0 * (double)PF_SMAX && dev < 1.0e-3;
+  // K = 16 form: the per-pair bound of the dropped a_hi . b_lo (k_ransac_pack16_b0) assumes |t| <= 2.002 smax
+  // (tcap > 0) and its constant term is centred by beta = smax^2, which comes back through c_h
+  if (tcap > 0.0) usable = usable && tn <= tcap * smax;
+  const double beta = tcap > 0.0 ? smax * smax : 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) usable = usable && fabs(a[k]) < 6.0e4;  // false for NaN
   union {
@@ -712,7 +774,7 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
   const double w = 2.0 * smax + tn;
   const double eps = 2.5e-5 * w * w + 6.0e-6 + 3.0 * dev * smax * smax + 1.000001 * drop;
   // rounded towards -inf so that the f32 value never tightens the test
-  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd(tt - (thr2 + eps)) : -INFINITY;
+  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd((tt + beta) - (thr2 + eps)) : -INFINITY;
 }
 
 // Upper bounds of the inlier counts.
@@ -735,6 +797,7 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
 // hardware requires.  The VALU side is the longer one (v_alignbit_b32 issues every ~4.5 cycles per
 // SIMD, tools/ubench/valu_rate.hip: 16 x 4.5 = 72 cycles against 64 for the MFMAs).  The unit is one asm block: the compiler's scheduler does not keep this order
 // (it hoists the dependent VALU ops and pays s_nop 10 per unit).
+template <int NM>   // MFMAs per unit: 2 = K 32 (a_hi . (b_hi + b_lo)), 1 = K 16 (a_hi . b_hi', rows of k_ransac_pack16<1> + _b0)
 __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* probs,
                                                           const int64_t* __restrict__ off16,
                                                           const _Float16* __restrict__ B16,
@@ -747,7 +810,8 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
                                                           unsigned long long* __restrict__ trace) {
   const unsigned long long t_start = trace ? wall_clock64() : 0ULL;
   const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ULL;
-  constexpr int STAGE_BYTES = PF_ROWS * PF_PITCH * 2;  // 15360
+  constexpr int PITCH = pf_pitch(NM);
+  constexpr int STAGE_BYTES = PF_ROWS * PITCH * 2;  // 15360 (K 32) / 9216 (K 16)
   constexpr int STAGE_KIB = STAGE_BYTES / 1024;        // 15 LDS-DMA instructions
   static_assert(STAGE_BYTES % 1024 == 0, "a stage must be whole 1-KiB LDS-DMA instructions");
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
@@ -794,9 +858,9 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
     bits[g] = 0u;
     cnt[g] = 0;
   }
-  const char* gsrc = reinterpret_cast<const char*>(B16 + off16[p] * PF_PITCH) + lane * 16;
+  const char* gsrc = reinterpret_cast<const char*>(B16 + off16[p] * PITCH) + lane * 16;
   auto issue_stage = [&](int b, int base) {
-    const char* g = gsrc + (int64_t)base * (PF_PITCH * 2);
+    const char* g = gsrc + (int64_t)base * (PITCH * 2);
 #pragma unroll
     for (int i = 0; i < (STAGE_KIB + 3) / 4; ++i) {
       const int piece = wave + 4 * i;  // wave-uniform
@@ -809,7 +873,32 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   static_assert(PF_NG == 2 && PF_ROWS == 192, "the unrolled schedule below is written for 12 units per stage");
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 S0, S1 = zero16, S2 = zero16;  // +0: the first two (dummy) extractions shift in zeros
-#define PF_UNIT(DST, SRC, G, A, COUNT) \
+#define PF_UNIT1(DST, SRC, G, A, COUNT) \
+  asm volatile( \
+      "v_mfma_f32_32x32x16_f16 %0, %2, %3, %4\n\t" \
+      "v_alignbit_b32 %1, %1, %5, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %6, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %7, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %8, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %9, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %10, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %11, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %12, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %13, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %14, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %15, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %16, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %17, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %18, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %19, 31\n\t" \
+      "v_alignbit_b32 %1, %1, %20, 31" \
+      : "=&v"(DST), "+v"(bits[G]) \
+      : "v"(A[0]), "v"(bop[G]), \
+        "v"(cin[G]), "v"(SRC[0]), "v"(SRC[1]), "v"(SRC[2]), "v"(SRC[3]), "v"(SRC[4]), "v"(SRC[5]), \
+        "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
+        "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15])); \
+  if (COUNT) cnt[G] += __popc(bits[G]);
+#define PF_UNIT2(DST, SRC, G, A, COUNT) \
   asm volatile( \
       "v_mfma_f32_32x32x16_f16 %0, %2, %4, %6\n\t" \
       "v_alignbit_b32 %1, %1, %7, 31\n\t" \
@@ -835,11 +924,17 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
         "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
         "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15])); \
   if (COUNT) cnt[G] += __popc(bits[G]);
+#define PF_UNIT(DST, SRC, G, A, COUNT)            \
+  if constexpr (NM == 2) {                        \
+    PF_UNIT2(DST, SRC, G, A, COUNT)               \
+  } else {                                        \
+    PF_UNIT1(DST, SRC, G, A, COUNT)               \
+  }
 #define PF_LOAD(A, TILE)                                                                          \
   {                                                                                               \
     const _Float16* arow_ = reinterpret_cast<const _Float16*>(lds + buf * STAGE_BYTES) +          \
-                            ((TILE) * 32 + col) * PF_PITCH + 8 * half;                            \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) A[m] =                                          \
+                            ((TILE) * 32 + col) * PITCH + 8 * half;                               \
+    _Pragma("unroll") for (int m = 0; m < NM; ++m) A[m] =                                         \
         *reinterpret_cast<const f16x8*>(arow_ + 16 * m);                                          \
   }
   if (beg < end) issue_stage(0, beg);
@@ -885,6 +980,8 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
     buf ^= 1;
   }
 #undef PF_UNIT
+#undef PF_UNIT1
+#undef PF_UNIT2
 #undef PF_LOAD
   if (trace && lane == 0) {
     unsigned hwid;
@@ -1316,6 +1413,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   const char* env_pf = getenv("CS_RANSAC_PREFILTER");
   const char* env_ck = getenv("CS_RANSAC_CHECK");
   const bool use_pf = !(env_pf && env_pf[0] == '0') && total > 0;
+  // CS_RANSAC_PF_K = 32: the two-MFMA form a_hi . (b_hi + b_lo); 16 (default, round 4): one MFMA, a_hi . b_hi with the
+  // dropped term bounded per pair (k_ransac_pack16_b0).  Same results either way (the exact kernels decide).
+  const int pf_nm = (getenv("CS_RANSAC_PF_K") && atoi(getenv("CS_RANSAC_PF_K")) == 32) ? 2 : 1;
+  // K = 16: largest |t| / smax a hypothesis may have to go through the prefilter (the others are counted exactly)
+  double pf_tcap = getenv("CS_RANSAC_PF_TCAP") ? atof(getenv("CS_RANSAC_PF_TCAP")) : 0.75;
+  if (!(pf_tcap > 0.01 && pf_tcap <= 2.002)) pf_tcap = 2.002;
+  if (pf_nm == 2) pf_tcap = 0.0;
   const bool check = use_pf && env_ck && env_ck[0] == '1';
   // first chunk (all hypotheses counted exactly: there is no best count to prune against yet) and first
   // prefiltered iteration.  Round 1 (f32 matrix-pipe exact kernel): 512 = 256, no difference; with the f64
@@ -1351,7 +1455,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   std::vector<int64_t> h_off16(n_prob + 1, 0);
   for (int p = 0; p < n_prob; ++p) h_off16[p + 1] = h_off16[p] + pf_padded(hp[p].m);
   const int64_t rows16 = h_off16[n_prob] ? h_off16[n_prob] : 1;
-  PoolBuf<_Float16> B16(pf_alloc ? (size_t)rows16 * PF_PITCH : 8), A16(pf_alloc ? (size_t)2 * n_prob * bmax * PF_K : 8);
+  PoolBuf<_Float16> B16(pf_alloc ? (size_t)rows16 * pf_pitch(pf_nm) : 8), A16(pf_alloc ? (size_t)2 * n_prob * bmax * PF_K : 8);
   PoolBuf<int64_t> off16(n_prob + 1);
   PoolBuf<float> c_h(pf_alloc ? (size_t)2 * n_prob * bmax : 1);
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)2 * n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
@@ -1383,8 +1487,15 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (pblocks > 64) pblocks = 64;
     CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
                                 hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ransac_pack16, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                       d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
+    if (pf_nm == 2) {
+      hipLaunchKernelGGL(k_ransac_pack16<2>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
+                         d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
+    } else {
+      hipLaunchKernelGGL(k_ransac_pack16<1>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
+                         d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
+      hipLaunchKernelGGL(k_ransac_pack16_b0, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
+                         d_probs, off16.p, d_src, d_tgt, pf_stat.p, pf_tcap, B16.p);
+    }
     CS_LAUNCH_CHECK();
   }
   // squared threshold (Open3D: max_correspondence_distance * max_correspondence_distance in double) and
@@ -1508,7 +1619,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
                          0, sh, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r,
-                         psplits > 1 ? cnt_up_r : (int32_t*)nullptr);
+                         psplits > 1 ? cnt_up_r : (int32_t*)nullptr, pf_tcap);
       if (sh != st) {   // the prefilter (side stream) follows the hypotheses (third stream)
         (void)hipEventRecord(hyp_done[par].e, sh);
         (void)hipStreamWaitEvent(st, hyp_done[par].e, 0);
@@ -1516,9 +1627,14 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       {
         ProfScope prof("ransac_pre", st);  // work units are added by the back half (state known there)
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
-        hipLaunchKernelGGL(k_ransac_prefilter, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
-                           A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
-                           (trace_it0 == it0) ? trace.p : nullptr);
+        if (pf_nm == 2)
+          hipLaunchKernelGGL(k_ransac_prefilter<2>, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+                             A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
+                             (trace_it0 == it0) ? trace.p : nullptr);
+        else
+          hipLaunchKernelGGL(k_ransac_prefilter<1>, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+                             A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
+                             (trace_it0 == it0) ? trace.p : nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
     }
