@@ -726,12 +726,16 @@ def roofline_of(fam, solo, args):
                    "knn": "2 N0 N1 16 (SURVEY 8d), peak = dense f16 MFMA",
                    "chamfer": "8 N0 N1, peak = f64 MFMA"}[dom]}
     if dom == "ransac_pre":
-        # the matrix pipe executes 32 f16 multiply-adds per (hypothesis, pair): a_hi (b_hi + b_lo)
-        r["achieved_executed"] = achieved * 64.0 / 30.0
+        # the matrix pipe executes K f16 multiply-adds per (hypothesis, pair): K = 16 (a_hi . b_hi', round 4 default) or
+        # 32 (a_hi . (b_hi + b_lo), CS_RANSAC_PF_K=32)
+        pf_k = 32 if os.environ.get("CS_RANSAC_PF_K", "16") == "32" else 16
+        ex = 2.0 * pf_k / 30.0
+        r["executed_flop_per_pair"] = 2 * pf_k
+        r["achieved_executed"] = achieved * ex
         r["frac_executed"] = r["achieved_executed"] / peak
         if solo and solo["launches"]:
             a_solo = solo["flop"] / (solo["ms"] * 1e-3) / 1e12
-            r["solo"] = {"achieved": a_solo, "frac": a_solo / peak, "frac_executed": a_solo * 64.0 / 30.0 / peak,
+            r["solo"] = {"achieved": a_solo, "frac": a_solo / peak, "frac_executed": a_solo * ex / peak,
                          "avg_launch_ms": solo["ms"] / solo["launches"], "launches": solo["launches"],
                          "note": "same kernel and inputs with CS_RANSAC_OVERLAP=0 CORSAIR_SPLIT_RANSAC=0 "
                                  "(nothing else on the GPU while it runs), extra untimed pass"}

@@ -569,6 +569,40 @@ __host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_
 // is +60000 (never counted).  stat[p] = {largest point norm, max |b_k| (k = 0..15)} of problem p as
 // float bit patterns (non-negative floats order like their bits), rounded up.
 // grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
+// Per-problem sums of the source and target points (f64 atomics; mu = sum / m is evaluated with the same expression by every
+// consumer).  The prefilter works in coordinates CENTRED per problem, s' = s - mu_s, q' = q - mu_q: the residual is the same,
+// R s' + t' - q' = R s + t - q with t' = t + R mu_s - mu_q (k_ransac_hyp16), but every magnitude the error bounds scale with
+// -- smax, W, |t'| = |c'_t - R c'_s| with c' the centroids of the ten sampled points in centred coordinates -- shrinks to the
+// spread of the problem's points.  The part-to-part problems of split_corr (utils/symmetry.py:145-179: a leg against a leg)
+// sit far from the origin; without the centring 30 % of their hypotheses exceeded the |t| cap of the K = 16 form.
+__global__ __launch_bounds__(256) void k_ransac_pair_sums(const RansacProb* __restrict__ probs, const float* __restrict__ src,
+                                                          const float* __restrict__ tgt, double* __restrict__ sums) {
+  const RansacProb pr = probs[blockIdx.y];
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pr.m; j += gridDim.x * blockDim.x) {
+    const int64_t i = pr.off + j;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a[c] += (double)src[3 * i + c];
+      a[3 + c] += (double)tgt[3 * i + c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a[c] += __shfl_xor(a[c], off);
+    if ((threadIdx.x & 63) == 0 && a[c] != 0.0) atomicAdd(&sums[blockIdx.y * 6 + c], a[c]);
+  }
+}
+__device__ __forceinline__ void pf_centre(const double* __restrict__ sums, int p, int m, double (&mu)[6]) {
+  const double dm = (double)(m > 0 ? m : 1);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double v = sums[p * 6 + c] / dm;
+    mu[c] = (v == v && fabs(v) < 1.0e30) ? v : 0.0;   // non-finite input: no centring (the rows are rejected by their norm)
+  }
+}
+
 // NM = 2: rows [bh | bl | pad] of the K = 32 form.  NM = 1 (round 4): rows [bh | pad] of the K = 16 form -- the matrix pipe
 // then evaluates a_hi . b_hi only, and what it drops, a_hi . b_lo, is bounded PER PAIR and taken out of the pair's constant
 // term b_0 (a_0 = 1 exactly) by k_ransac_pack16_b0 below, so the sign test stays an upper bound (see there).
@@ -577,10 +611,13 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
                                                        const int64_t* __restrict__ off16,
                                                        const float* __restrict__ src,
                                                        const float* __restrict__ tgt,
+                                                       const double* __restrict__ sums,
                                                        _Float16* __restrict__ B16,
                                                        unsigned* __restrict__ stat) {
   __shared__ float red[4][PF_STAT];
   const RansacProb pr = probs[blockIdx.y];
+  double mu[6];
+  pf_centre(sums, blockIdx.y, pr.m, mu);
   const int mpad = (int)pf_padded(pr.m);
   float mx[PF_STAT];
 #pragma unroll
@@ -595,8 +632,8 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
     for (int k = 0; k < 5; ++k) row.v[k] = make_uint4(0u, 0u, 0u, 0u);
     if (j < pr.m) {
       const int64_t i = pr.off + j;
-      const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-      const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
+      const double sx = src[3 * i] - mu[0], sy = src[3 * i + 1] - mu[1], sz = src[3 * i + 2] - mu[2];
+      const double qx = tgt[3 * i] - mu[3], qy = tgt[3 * i + 1] - mu[4], qz = tgt[3 * i + 2] - mu[5];
       const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
       double b[16];
       b[0] = ss + qq;
@@ -659,17 +696,20 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 __global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __restrict__ probs,
                                                           const int64_t* __restrict__ off16,
                                                           const float* __restrict__ src, const float* __restrict__ tgt,
+                                                          const double* __restrict__ sums,
                                                           const unsigned* __restrict__ stat, double tcap,
                                                           _Float16* __restrict__ B16) {
   const RansacProb pr = probs[blockIdx.y];
+  double mu[6];
+  pf_centre(sums, blockIdx.y, pr.m, mu);
   const double smax = (double)__uint_as_float(stat[blockIdx.y * PF_STAT]);
   if (!(smax <= (double)PF_SMAX)) return;   // the problem bypasses the prefilter (every hypothesis unusable)
   const double beta = smax * smax;
   const double a_rot = 2.002 * (1.0 + 0x1p-11), a_t = 2.0 * tcap * smax * 1.0005 * (1.0 + 0x1p-11);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pr.m; j += gridDim.x * blockDim.x) {
     const int64_t i = pr.off + j;
-    const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-    const double qx = tgt[3 * i], qy = tgt[3 * i + 1], qz = tgt[3 * i + 2];
+    const double sx = src[3 * i] - mu[0], sy = src[3 * i + 1] - mu[1], sz = src[3 * i + 2] - mu[2];
+    const double qx = tgt[3 * i] - mu[3], qy = tgt[3 * i + 1] - mu[4], qz = tgt[3 * i + 2] - mu[5];
     const double ss = sx * sx + sy * sy + sz * sz, qq = qx * qx + qy * qy + qz * qz;
     const double b[16] = {ss + qq, sx, sy, sz, qx * sx, qx * sy, qx * sz, qy * sx, qy * sy, qy * sz,
                           qz * sx, qz * sy, qz * sz, qx, qy, qz};
@@ -710,8 +750,8 @@ __global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __re
 // with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
 // a zero row: every pair counts, it always survives to the exact kernel.
 __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
-                               const unsigned* __restrict__ stat, int it0, int bcount, int bmax,
-                               double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
+                               const unsigned* __restrict__ stat, const double* __restrict__ sums, int it0, int bcount,
+                               int bmax, double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
                                int32_t* __restrict__ cnt_zero, double tcap) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,6 +768,14 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
 #pragma unroll
     for (int b = 0; b < 3; ++b) R[a][b] = hp[(int64_t)(4 * a + b) * bmax];
     t[a] = hp[(int64_t)(4 * a + 3) * bmax];
+  }
+  // the pair image is in centred coordinates: t' = t + R mu_s - mu_q (see k_ransac_pair_sums); the f64 rounding of these
+  // nine operations (<= 1e-15 (|t| + |mu|)) sits far inside the 6e-6 of eps
+  {
+    double mu[6];
+    pf_centre(sums, p, pr.m, mu);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a] = t[a] + (R[a][0] * mu[0] + R[a][1] * mu[1] + R[a][2] * mu[2]) - mu[3 + a];
   }
   const double smax = (double)__uint_as_float(stat[p * PF_STAT]);
   const double tt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
@@ -1460,9 +1508,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   PoolBuf<float> c_h(pf_alloc ? (size_t)2 * n_prob * bmax : 1);
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)2 * n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned> pf_stat((size_t)n_prob * PF_STAT);
+  PoolBuf<double> pf_sums((size_t)n_prob * 6);
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
-  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && pf_stat.p &&
+  CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && pf_stat.p && pf_sums.p &&
                  exact_dbg.p && chk_stats.p,
              CS_ERR_HIP, "cs_ransac_batch: scratch allocation failed");
   std::vector<int32_t> h_surv(n_prob), h_xcd[2];
@@ -1487,14 +1536,17 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (pblocks > 64) pblocks = 64;
     CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
                                 hipMemcpyHostToDevice, s));
+    CS_HIP_CHECK(hipMemsetAsync(pf_sums.p, 0, sizeof(double) * n_prob * 6, s));
+    hipLaunchKernelGGL(k_ransac_pair_sums, dim3((unsigned)std::min(pblocks, 16), (unsigned)n_prob), dim3(256), 0, s, d_probs,
+                       d_src, d_tgt, pf_sums.p);
     if (pf_nm == 2) {
       hipLaunchKernelGGL(k_ransac_pack16<2>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                         d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
+                         d_probs, off16.p, d_src, d_tgt, pf_sums.p, B16.p, pf_stat.p);
     } else {
       hipLaunchKernelGGL(k_ransac_pack16<1>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                         d_probs, off16.p, d_src, d_tgt, B16.p, pf_stat.p);
+                         d_probs, off16.p, d_src, d_tgt, pf_sums.p, B16.p, pf_stat.p);
       hipLaunchKernelGGL(k_ransac_pack16_b0, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
-                         d_probs, off16.p, d_src, d_tgt, pf_stat.p, pf_tcap, B16.p);
+                         d_probs, off16.p, d_src, d_tgt, pf_sums.p, pf_stat.p, pf_tcap, B16.p);
     }
     CS_LAUNCH_CHECK();
   }
@@ -1618,7 +1670,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       if (psplits > 16) psplits = 16;
       while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
       hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, sh, d_probs, hyp_r, pf_stat.p, it0, b, bmax, thr2, A16_r, c_h_r,
+                         0, sh, d_probs, hyp_r, pf_stat.p, pf_sums.p, it0, b, bmax, thr2, A16_r, c_h_r,
                          psplits > 1 ? cnt_up_r : (int32_t*)nullptr, pf_tcap);
       if (sh != st) {   // the prefilter (side stream) follows the hypotheses (third stream)
         (void)hipEventRecord(hyp_done[par].e, sh);
@@ -1701,9 +1753,17 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       {
         ProfScope prof("ransac_eval", s);
         // the previous round's survivor counts pick the kernel (both are exact for any count)
-        if (max_surv_prev <= 128) {  // (32 / 64 / 128 / 256 measured: 128 is the fastest by ~1 %)
-          hipLaunchKernelGGL(k_ransac_count_few, dim3(8, (unsigned)n_prob, 8), dim3(256), 0, s, d_probs, pk.p,
-                             tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
+        // (round 3, K = 32 prefilter: 32 / 64 / 128 / 256 measured, 128 the fastest by ~1 %.  The K = 16 form of round 4
+        // leaves 3 - 4x the survivors, ~16 per problem and round on the chair shape: the list kernel -- one workgroup of
+        // 256 hypothesis lanes per problem -- then ran in every fourth round at 670 us)
+        static const int few_max = getenv("CS_RANSAC_FEW_MAX") ? std::max(atoi(getenv("CS_RANSAC_FEW_MAX")), 1) : 1024;
+        if (max_surv_prev <= few_max) {
+          // pair slices short enough for a thread to keep its pairs in registers across the survivors (8 per thread)
+          int fslices = 8;
+          while (fslices < 32 && m_max > fslices * 2048) fslices *= 2;
+          const int fslots = max_surv_prev <= 128 ? 8 : (max_surv_prev <= 256 ? 16 : 32);
+          hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
+                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
