@@ -802,6 +802,7 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
   // K = 16 form: the per-pair bound of the dropped a_hi . b_lo (k_ransac_pack16_b0) assumes |t| <= 2.002 smax
   // (tcap > 0) and its constant term is centred by beta = smax^2, which comes back through c_h
   if (tcap > 0.0) usable = usable && tn <= tcap * smax;
+  usable = usable && thr2 < 3.0e4;   // the padding rows (b_0 = 60000) must stay positive: c_h > -60000
   const double beta = tcap > 0.0 ? smax * smax : 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) usable = usable && fabs(a[k]) < 6.0e4;  // false for NaN
@@ -822,7 +823,9 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
   const double w = 2.0 * smax + tn;
   const double eps = 2.5e-5 * w * w + 6.0e-6 + 3.0 * dev * smax * smax + 1.000001 * drop;
   // rounded towards -inf so that the f32 value never tightens the test
-  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd((tt + beta) - (thr2 + eps)) : -INFINITY;
+  // unusable: a zero row and c_h = -1, so every row (padding included) counts and the hypothesis survives.  (FINITE: the
+  // round-toward-minus-infinity counters of k_ransac_prefilter<1, true> add the results themselves.)
+  c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd((tt + beta) - (thr2 + eps)) : -1.0f;
 }
 
 // Upper bounds of the inlier counts.
@@ -845,7 +848,12 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
 // hardware requires.  The VALU side is the longer one (v_alignbit_b32 issues every ~4.5 cycles per
 // SIMD, tools/ubench/valu_rate.hip: 16 x 4.5 = 72 cycles against 64 for the MFMAs).  The unit is one asm block: the compiler's scheduler does not keep this order
 // (it hoists the dependent VALU ops and pays s_nop 10 per unit).
-template <int NM>   // MFMAs per unit: 2 = K 32 (a_hi . (b_hi + b_lo)), 1 = K 16 (a_hi . b_hi', rows of k_ransac_pack16<1> + _b0)
+// RTN (with NM = 1): the signs are counted by the results THEMSELVES -- under round-toward-minus-infinity (MODE.fp_round)
+// and with a counter in [2^63, 2^64), whose ulp is 2^40, `v_add_f32 cnt, acc, cnt` subtracts exactly 2^40 iff acc < 0 for
+// any |acc| < 2^40 (tools/ubench/rtn_count.hip: edge cases incl. -0 and denormals) -- one FULL-RATE VALU op per result
+// instead of a 4.5-cycle v_alignbit.  Full-rate ops do not overlap with the matrix pipe, but the K = 16 unit has only one
+// MFMA: 32 + 16 x 2.3 = 69 cycles against 72+ (tools/ubench/pf_k16_mix.hip: 29.2 vs 32.8 ns per unit per SIMD).
+template <int NM, bool RTN>   // NM = MFMAs per unit: 2 = K 32 (a_hi . (b_hi + b_lo)), 1 = K 16 (a_hi . b_hi', k_ransac_pack16<1> + _b0)
 __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* probs,
                                                           const int64_t* __restrict__ off16,
                                                           const _Float16* __restrict__ B16,
@@ -899,12 +907,17 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   const int per = ((mpad / PF_ROWS + splits - 1) / splits) * PF_ROWS;
   const int beg = split * per;
   const int end = min(mpad, beg + per);
+  static_assert(!RTN || NM == 1, "the add-based sign count is written for the one-MFMA unit");
   unsigned bits[PF_NG];
   int cnt[PF_NG];
+  constexpr float RTN_C0 = 0x1p64f - 0x1p40f;   // 2^64 - 2^40: all 24 significand bits set, ulp 2^40
+  float fc[PF_NG][2];
 #pragma unroll
   for (int g = 0; g < PF_NG; ++g) {
     bits[g] = 0u;
     cnt[g] = 0;
+    fc[g][0] = RTN_C0;
+    fc[g][1] = RTN_C0;
   }
   const char* gsrc = reinterpret_cast<const char*>(B16 + off16[p] * PITCH) + lane * 16;
   auto issue_stage = [&](int b, int base) {
@@ -972,9 +985,34 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
         "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
         "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15])); \
   if (COUNT) cnt[G] += __popc(bits[G]);
+#define PF_UNITR(DST, SRC, G, GC, A) \
+  asm volatile( \
+      "v_mfma_f32_32x32x16_f16 %0, %3, %4, %5\n\t" \
+      "v_add_f32 %1, %6, %1\n\t" \
+      "v_add_f32 %2, %7, %2\n\t" \
+      "v_add_f32 %1, %8, %1\n\t" \
+      "v_add_f32 %2, %9, %2\n\t" \
+      "v_add_f32 %1, %10, %1\n\t" \
+      "v_add_f32 %2, %11, %2\n\t" \
+      "v_add_f32 %1, %12, %1\n\t" \
+      "v_add_f32 %2, %13, %2\n\t" \
+      "v_add_f32 %1, %14, %1\n\t" \
+      "v_add_f32 %2, %15, %2\n\t" \
+      "v_add_f32 %1, %16, %1\n\t" \
+      "v_add_f32 %2, %17, %2\n\t" \
+      "v_add_f32 %1, %18, %1\n\t" \
+      "v_add_f32 %2, %19, %2\n\t" \
+      "v_add_f32 %1, %20, %1\n\t" \
+      "v_add_f32 %2, %21, %2" \
+      : "=&v"(DST), "+v"(fc[GC][0]), "+v"(fc[GC][1]) \
+      : "v"(A[0]), "v"(bop[G]), \
+        "v"(cin[G]), "v"(SRC[0]), "v"(SRC[1]), "v"(SRC[2]), "v"(SRC[3]), "v"(SRC[4]), "v"(SRC[5]), \
+        "v"(SRC[6]), "v"(SRC[7]), "v"(SRC[8]), "v"(SRC[9]), "v"(SRC[10]), "v"(SRC[11]), \
+        "v"(SRC[12]), "v"(SRC[13]), "v"(SRC[14]), "v"(SRC[15]));
 #define PF_UNIT(DST, SRC, G, A, COUNT)            \
   if constexpr (NM == 2) {                        \
     PF_UNIT2(DST, SRC, G, A, COUNT)               \
+  } else if constexpr (RTN) {                     \
   } else {                                        \
     PF_UNIT1(DST, SRC, G, A, COUNT)               \
   }
@@ -986,6 +1024,9 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
         *reinterpret_cast<const f16x8*>(arow_ + 16 * m);                                          \
   }
   if (beg < end) issue_stage(0, beg);
+  // f32 rounding toward -inf from here on (MODE[1:0]); nothing below depends on round-to-nearest: the MFMA results may
+  // come out one ulp lower, which can only add to the count
+  if constexpr (RTN) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2");
   const unsigned long long t_loop = trace ? wall_clock64() : 0ULL;
   unsigned long long t_wait_dma = 0, t_wait_bar = 0;
   int buf = 0;
@@ -1002,7 +1043,34 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
       t_wait_bar += tw2 - tw1;
     }
     if (base + PF_ROWS < end) issue_stage(buf ^ 1, base + PF_ROWS);
-    if (wave_live) {
+    if constexpr (RTN) {
+      if (wave_live) {
+        // TWO accumulator sets: S0 always holds group 0, S1 group 1; unit k = (tile k / 2, group k % 2) writes its group's
+        // set and adds the OTHER set = the results of unit k - 1 into that group's counters.  Between the MFMA of unit
+        // k - 1 and the first read of its results lie its own 16 adds and the MFMA of unit k: 17 instructions, beyond
+        // the 11 wait states an 8-pass MFMA needs.  (A third set as in the v_alignbit schedule costs 16 VGPRs: 142, three
+        // waves per SIMD.)
+        f16x8 aX[2], aY[2];
+        PF_LOAD(aX, 0)
+        PF_LOAD(aY, 1)
+        PF_UNITR(S0, S1, 0, 1, aX)
+        PF_UNITR(S1, S0, 1, 0, aX)
+        PF_LOAD(aX, 2)
+        PF_UNITR(S0, S1, 0, 1, aY)
+        PF_UNITR(S1, S0, 1, 0, aY)
+        PF_LOAD(aY, 3)
+        PF_UNITR(S0, S1, 0, 1, aX)
+        PF_UNITR(S1, S0, 1, 0, aX)
+        PF_LOAD(aX, 4)
+        PF_UNITR(S0, S1, 0, 1, aY)
+        PF_UNITR(S1, S0, 1, 0, aY)
+        PF_LOAD(aY, 5)
+        PF_UNITR(S0, S1, 0, 1, aX)
+        PF_UNITR(S1, S0, 1, 0, aX)
+        PF_UNITR(S0, S1, 0, 1, aY)
+        PF_UNITR(S1, S0, 1, 0, aY)
+      }
+    } else if (wave_live) {
       // unit k writes set k % 3 and extracts set (k + 1) % 3 = unit k-2 = (tile t-1, same group);
       // 32 fresh sign bits are counted whenever tile t-1 is odd
       f16x8 aX[2], aY[2];
@@ -1028,6 +1096,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
     buf ^= 1;
   }
 #undef PF_UNIT
+#undef PF_UNITR
 #undef PF_UNIT1
 #undef PF_UNIT2
 #undef PF_LOAD
@@ -1049,12 +1118,22 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   if (!wave_live || beg >= end) return;
   // drain: the asm blocks hide their MFMAs from the compiler's hazard recognizer
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S1), "+v"(S2));
+  if constexpr (RTN) {
+    // the last unit (group 1) is the only one not counted yet
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bits[0] = __builtin_amdgcn_alignbit(bits[0], __float_as_uint(S1[r]), 31);
-  cnt[0] += __popc(bits[0]);
+    for (int r = 0; r < 16; ++r) asm volatile("v_add_f32 %0, %1, %0" : "+v"(fc[1][r & 1]) : "v"(S1[r]));
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" ::: "memory");
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bits[1] = __builtin_amdgcn_alignbit(bits[1], __float_as_uint(S2[r]), 31);
-  cnt[1] += __popc(bits[1]);
+    for (int g = 0; g < PF_NG; ++g)   // (C0 - fc) is count * 2^40 exactly: both operands are multiples of 2^40 below 2^64
+      cnt[g] = (int)((RTN_C0 - fc[g][0]) * 0x1p-40f) + (int)((RTN_C0 - fc[g][1]) * 0x1p-40f);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits[0] = __builtin_amdgcn_alignbit(bits[0], __float_as_uint(S1[r]), 31);
+    cnt[0] += __popc(bits[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits[1] = __builtin_amdgcn_alignbit(bits[1], __float_as_uint(S2[r]), 31);
+    cnt[1] += __popc(bits[1]);
+  }
 #pragma unroll
   for (int g = 0; g < PF_NG; ++g) {
     const int c = cnt[g] + __shfl_xor(cnt[g], 32);
@@ -1468,6 +1547,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   double pf_tcap = getenv("CS_RANSAC_PF_TCAP") ? atof(getenv("CS_RANSAC_PF_TCAP")) : 0.75;
   if (!(pf_tcap > 0.01 && pf_tcap <= 2.002)) pf_tcap = 2.002;
   if (pf_nm == 2) pf_tcap = 0.0;
+  // CS_RANSAC_PF_COUNT=alignbit: the sign history of rounds 1-3 instead of the add-based count (K = 16 only)
+  const bool pf_rtn = pf_nm == 1 && !(getenv("CS_RANSAC_PF_COUNT") && getenv("CS_RANSAC_PF_COUNT")[0] == 'a');
   const bool check = use_pf && env_ck && env_ck[0] == '1';
   // first chunk (all hypotheses counted exactly: there is no best count to prune against yet) and first
   // prefiltered iteration.  Round 1 (f32 matrix-pipe exact kernel): 512 = 256, no difference; with the f64
@@ -1680,11 +1761,15 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         ProfScope prof("ransac_pre", st);  // work units are added by the back half (state known there)
         const unsigned nblk = (unsigned)(8 * pslots * ptiles * psplits);
         if (pf_nm == 2)
-          hipLaunchKernelGGL(k_ransac_prefilter<2>, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+          hipLaunchKernelGGL((k_ransac_prefilter<2, false>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+                             A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
+                             (trace_it0 == it0) ? trace.p : nullptr);
+        else if (pf_rtn)
+          hipLaunchKernelGGL((k_ransac_prefilter<1, true>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
                              A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
                              (trace_it0 == it0) ? trace.p : nullptr);
         else
-          hipLaunchKernelGGL(k_ransac_prefilter<1>, dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
+          hipLaunchKernelGGL((k_ransac_prefilter<1, false>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
                              A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
                              (trace_it0 == it0) ? trace.p : nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
