@@ -1218,12 +1218,22 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
       if (i >= i1) ps[j][3] = 1.0e30f;  // far-away target: never an inlier
     }
   }
+  // the next survivor's hypothesis is requested before the current one is evaluated: list entry -> twelve strided f64
+  // loads are two dependent trips to L2 (~2 us), as long as the 8 x 22 f64 operations per thread they feed
+  int hn = hlist[(int64_t)p * bmax + blockIdx.z];
+  double Rn[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
   for (int c = blockIdx.z; c < nlist; c += gridDim.z) {
-    const int h = hlist[(int64_t)p * bmax + c];
-    const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
+    const int h = hn;
     double R[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) R[e] = hp[(int64_t)e * bmax];
+    for (int e = 0; e < 12; ++e) R[e] = Rn[e];
+    if (c + (int)gridDim.z < nlist) {
+      hn = hlist[(int64_t)p * bmax + c + gridDim.z];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
+    }
     int cnt = 0;
     unsigned long long err = 0;  // fixed-point squared error of the inliers (exact integer sum, as k_ransac_err)
     auto one = [&](float sx, float sy, float sz, float qx, float qy, float qz) {
