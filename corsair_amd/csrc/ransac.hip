@@ -1852,11 +1852,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         // leaves 3 - 4x the survivors, ~16 per problem and round on the chair shape: the list kernel -- one workgroup of
         // 256 hypothesis lanes per problem -- then ran in every fourth round at 670 us)
         static const int few_max = getenv("CS_RANSAC_FEW_MAX") ? std::max(atoi(getenv("CS_RANSAC_FEW_MAX")), 1) : 1024;
-        if (max_surv_prev <= few_max) {
+        // (the first prefiltered round has no previous count, but a chunk of b <= few_max hypotheses cannot leave more)
+        if (max_surv_prev <= few_max || b <= few_max) {
           // pair slices short enough for a thread to keep its pairs in registers across the survivors (8 per thread)
           int fslices = 8;
           while (fslices < 32 && m_max > fslices * 2048) fslices *= 2;
-          const int fslots = max_surv_prev <= 128 ? 8 : (max_surv_prev <= 256 ? 16 : 32);
+          const int surv_cap = std::min(max_surv_prev, b);
+          const int fslots = surv_cap <= 128 ? 8 : (surv_cap <= 256 ? 16 : 32);
           hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
                              d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;
