@@ -1858,7 +1858,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           int fslices = 8;
           while (fslices < 32 && m_max > fslices * 2048) fslices *= 2;
           const int surv_cap = std::min(max_surv_prev, b);
-          const int fslots = surv_cap <= 128 ? 8 : (surv_cap <= 256 ? 16 : 32);
+          // survivor slots per (slice, problem): a workgroup loads its pairs once and walks its share of the survivors, so
+          // FEW slots amortise the load (chair, same box: 2 / 4 / 8 / 16 slots -> 1 431 / 1 454 / 1 424 / 1 370 queries/s)
+          int fslots = surv_cap <= 256 ? 4 : 8;
+          if (getenv("CS_RANSAC_FEW_SLOTS")) fslots = std::max(1, atoi(getenv("CS_RANSAC_FEW_SLOTS")));
+          if (getenv("CS_RANSAC_FEW_SLICES")) fslices = std::max(1, atoi(getenv("CS_RANSAC_FEW_SLICES")));
           hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
                              d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
           err_known = true;
