@@ -569,17 +569,19 @@ __host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_
 // is +60000 (never counted).  stat[p] = {largest point norm, max |b_k| (k = 0..15)} of problem p as
 // float bit patterns (non-negative floats order like their bits), rounded up.
 // grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
-// Per-problem sums of the source and target points (f64 atomics; mu = sum / m is evaluated with the same expression by every
-// consumer).  The prefilter works in coordinates CENTRED per problem, s' = s - mu_s, q' = q - mu_q: the residual is the same,
+// Per-problem sums of the source and target points (mu = sum / m is evaluated with the same expression by every consumer).  The prefilter works in coordinates CENTRED per problem, s' = s - mu_s, q' = q - mu_q: the residual is the same,
 // R s' + t' - q' = R s + t - q with t' = t + R mu_s - mu_q (k_ransac_hyp16), but every magnitude the error bounds scale with
 // -- smax, W, |t'| = |c'_t - R c'_s| with c' the centroids of the ten sampled points in centred coordinates -- shrinks to the
 // spread of the problem's points.  The part-to-part problems of split_corr (utils/symmetry.py:145-179: a leg against a leg)
 // sit far from the origin; without the centring 30 % of their hypotheses exceeded the |t| cap of the K = 16 form.
 __global__ __launch_bounds__(256) void k_ransac_pair_sums(const RansacProb* __restrict__ probs, const float* __restrict__ src,
                                                           const float* __restrict__ tgt, double* __restrict__ sums) {
-  const RansacProb pr = probs[blockIdx.y];
+  // ONE workgroup per problem and a fixed reduction order: the means -- and with them the prefilter's survivor sets -- are
+  // the same in every run (an atomic accumulation made the survivor counts of otherwise identical runs differ by 1e-4)
+  __shared__ double red[4][6];
+  const RansacProb pr = probs[blockIdx.x];
   double a[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pr.m; j += gridDim.x * blockDim.x) {
+  for (int j = threadIdx.x; j < pr.m; j += 256) {
     const int64_t i = pr.off + j;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -591,8 +593,10 @@ __global__ __launch_bounds__(256) void k_ransac_pair_sums(const RansacProb* __re
   for (int c = 0; c < 6; ++c) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) a[c] += __shfl_xor(a[c], off);
-    if ((threadIdx.x & 63) == 0 && a[c] != 0.0) atomicAdd(&sums[blockIdx.y * 6 + c], a[c]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = a[c];
   }
+  __syncthreads();
+  if (threadIdx.x < 6) sums[blockIdx.x * 6 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __device__ __forceinline__ void pf_centre(const double* __restrict__ sums, int p, int m, double (&mu)[6]) {
   const double dm = (double)(m > 0 ? m : 1);
@@ -863,7 +867,8 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
                                                           const int32_t* __restrict__ xcd_prob,
                                                           const XcdTab xcd_tab, int slots, int tiles,
                                                           int32_t* __restrict__ cnt_up,
-                                                          unsigned long long* __restrict__ trace) {
+                                                          unsigned long long* __restrict__ trace,
+                                                          const int32_t* __restrict__ n_list) {
   const unsigned long long t_start = trace ? wall_clock64() : 0ULL;
   const unsigned long long c_start = trace ? __builtin_amdgcn_s_memtime() : 0ULL;
   constexpr int PITCH = pf_pitch(NM);
@@ -881,21 +886,25 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   const int split = inner - tile * splits;
   const RansacProb pr = prob_view(probs, p);
   if (pr.done) return;
-  if (it0 + tile * PF_HYP >= pr.est_k || tile * PF_HYP >= bcount) return;
+  // n_list: the hypotheses are a COMPACT per-problem list of n_list[p] rows (second stage over the survivors: rows
+  // gathered by k_ransac_stage2_gather, bmax = its row capacity) instead of the iterations it0 .. it0 + bcount of a chunk
+  if (n_list) bcount = min(n_list[p], bmax);
+  const int ek_rel = n_list ? 0x7fffffff : pr.est_k - it0;   // hypotheses at or beyond it are past the iteration bound
+  if (tile * PF_HYP >= ek_rel || tile * PF_HYP >= bcount) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
   const int col = lane & 31;
   const int h0 = tile * PF_HYP + wave * 32 * PF_NG;
-  const bool wave_live = h0 < bcount && it0 + h0 < pr.est_k;
+  const bool wave_live = h0 < bcount && h0 < ek_rel;
   f16x8 bop[PF_NG];
   f32x16 cin[PF_NG];
 #pragma unroll
   for (int g = 0; g < PF_NG; ++g) {
     // hypotheses past the chunk / bound read a valid row; their result is not stored
     int hh = h0 + 32 * g + col;
-    if (hh >= bcount || it0 + hh >= pr.est_k) hh = wave_live ? h0 : 0;
+    if (hh >= bcount || hh >= ek_rel) hh = wave_live ? h0 : 0;
     const _Float16* row = A16 + ((int64_t)p * bmax + hh) * PF_K + 8 * half;
     bop[g] = *reinterpret_cast<const f16x8*>(row);
     const float c = c_h[(int64_t)p * bmax + hh];
@@ -1138,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   for (int g = 0; g < PF_NG; ++g) {
     const int c = cnt[g] + __shfl_xor(cnt[g], 32);
     const int h = h0 + 32 * g + col;
-    if (half == 0 && h < bcount && it0 + h < pr.est_k) {
+    if (half == 0 && h < bcount && h < ek_rel) {
       if (splits == 1)
         cnt_up[(int64_t)p * bmax + h] = c;
       else
@@ -1162,6 +1171,54 @@ __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const i
     const int slot = atomicAdd(&n_surv[p], 1);
     hlist[(int64_t)p * bmax + slot] = h;
     err_by_h[(int64_t)p * bmax + h] = 0;  // accumulated by k_ransac_count_few
+  }
+}
+
+// ---- second stage (round 4): the K = 16 bound leaves 3 - 4x the survivors of the K = 32 bound; the survivors of a round --
+// a compact list of ~16 hypotheses per problem -- go through the K = 32 form (a_hi . (b_hi + b_lo), same a_hi rows, same
+// eps_h) before they are counted exactly.  1.5 % of the matrix work of a first-stage launch.
+constexpr int PF_S2_CAP = 1024;   // rows per problem of the compact list (= the largest list the few-survivor kernel takes)
+// rows of the survivors, compacted: A16s[p][slot] = A16[p][hlist[p][slot]], c_hs = c_h - beta (the K = 32 image is not
+// centred by beta; the difference of two floats within a factor of two of each other is exact, and 6e-6 of eps_h covers an
+// ulp otherwise); clears the second-stage counters.  grid: (PF_S2_CAP / 256, n_prob).
+__global__ void k_ransac_stage2_gather(const RansacProb* __restrict__ probs, const int32_t* __restrict__ hlist,
+                                       const int32_t* __restrict__ n_surv, int bmax, const _Float16* __restrict__ A16,
+                                       const float* __restrict__ c_h, const unsigned* __restrict__ stat, double tcap,
+                                       _Float16* __restrict__ A16s, float* __restrict__ c_hs,
+                                       int32_t* __restrict__ cnt2, int32_t* __restrict__ n_surv2) {
+  const int p = blockIdx.y;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot == 0) n_surv2[p] = 0;
+  if (probs[p].done) return;
+  const int n = min(n_surv[p], PF_S2_CAP);
+  if (slot >= n) return;
+  const int h = hlist[(int64_t)p * bmax + slot];
+  const uint4* src = reinterpret_cast<const uint4*>(A16 + ((int64_t)p * bmax + h) * PF_K);
+  uint4* dst = reinterpret_cast<uint4*>(A16s + ((int64_t)p * PF_S2_CAP + slot) * PF_K);
+  dst[0] = src[0];
+  dst[1] = src[1];
+  const double smax = (double)__uint_as_float(stat[p * PF_STAT]);
+  const double beta = tcap > 0.0 ? smax * smax : 0.0;   // the double k_ransac_hyp16 added
+  // (c - beta) in double is exact; narrowing toward -inf never tightens the test.  An unusable hypothesis (c_h = -1, zero
+  // row) stays negative: every row counts again
+  c_hs[(int64_t)p * PF_S2_CAP + slot] = __double2float_rd((double)c_h[(int64_t)p * bmax + h] - beta);
+  cnt2[(int64_t)p * PF_S2_CAP + slot] = 0;
+}
+// survivors of the second stage: hlist2 = the entries of hlist whose K = 32 bound still reaches the carried best count
+__global__ void k_ransac_stage2_survivors(const RansacProb* __restrict__ probs, const int32_t* __restrict__ hlist,
+                                          const int32_t* __restrict__ n_surv, int bmax, const int32_t* __restrict__ cnt2,
+                                          int32_t* __restrict__ hlist2, int32_t* __restrict__ n_surv2,
+                                          unsigned long long* __restrict__ total2) {
+  const int p = blockIdx.y;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const RansacProb pr = probs[p];
+  if (pr.done) return;
+  if (slot >= n_surv[p]) return;
+  // entries beyond the capacity of the compact list were not looked at by the second stage: they pass unfiltered
+  if (slot >= PF_S2_CAP || cnt2[(int64_t)p * PF_S2_CAP + slot] >= pr.best_cnt) {
+    const int o = atomicAdd(&n_surv2[p], 1);
+    hlist2[(int64_t)p * bmax + o] = hlist[(int64_t)p * bmax + slot];
+    atomicAdd(total2, 1ULL);
   }
 }
 
@@ -1194,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
                                                           int32_t* __restrict__ res_cnt,
                                                           unsigned long long* __restrict__ err_by_h,
                                                           const int32_t* __restrict__ hlist,
-                                                          const int32_t* __restrict__ n_surv) {
+                                                          const int32_t* __restrict__ n_surv, int list_stride) {
   const int p = blockIdx.y;
   const RansacProb pr = probs[p];
   if (pr.done) return;
@@ -1220,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
   }
   // the next survivor's hypothesis is requested before the current one is evaluated: list entry -> twelve strided f64
   // loads are two dependent trips to L2 (~2 us), as long as the 8 x 22 f64 operations per thread they feed
-  int hn = hlist[(int64_t)p * bmax + blockIdx.z];
+  int hn = hlist[(int64_t)p * list_stride + blockIdx.z];
   double Rn[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
@@ -1230,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
 #pragma unroll
     for (int e = 0; e < 12; ++e) R[e] = Rn[e];
     if (c + (int)gridDim.z < nlist) {
-      hn = hlist[(int64_t)p * bmax + c + gridDim.z];
+      hn = hlist[(int64_t)p * list_stride + c + gridDim.z];
 #pragma unroll
       for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
     }
@@ -1600,6 +1657,16 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   PoolBuf<int32_t> cnt_up(pf_alloc ? (size_t)2 * n_prob * bmax : 1), hlist(pf_alloc ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned> pf_stat((size_t)n_prob * PF_STAT);
   PoolBuf<double> pf_sums((size_t)n_prob * 6);
+  // second stage (K = 32 on the compacted survivors of the K = 16 stage; CS_RANSAC_STAGE2=0 switches it off)
+  const bool stage2 = pf_alloc && pf_nm == 1 && !(getenv("CS_RANSAC_STAGE2") && getenv("CS_RANSAC_STAGE2")[0] == '0');
+  PoolBuf<_Float16> B32(stage2 ? (size_t)rows16 * PF_PITCH : 8), A16s(stage2 ? (size_t)n_prob * PF_S2_CAP * PF_K : 8);
+  PoolBuf<float> c_hs(stage2 ? (size_t)n_prob * PF_S2_CAP : 1);
+  PoolBuf<int32_t> cnt2(stage2 ? (size_t)n_prob * PF_S2_CAP : 1), hlist2(stage2 ? (size_t)n_prob * bmax : 1),
+      n_surv2((size_t)n_prob);
+  PoolBuf<unsigned> pf_stat2((size_t)n_prob * PF_STAT);   // (the K = 32 pack writes the same statistics again: scratch)
+  PoolBuf<unsigned long long> s2_total(1);
+  CS_REQUIRE(B32.p && A16s.p && c_hs.p && cnt2.p && hlist2.p && n_surv2.p && pf_stat2.p && s2_total.p, CS_ERR_HIP,
+             "cs_ransac_batch: scratch allocation failed");
   PoolBuf<int32_t> exact_dbg(check ? (size_t)n_prob * bmax : 1);
   PoolBuf<unsigned long long> chk_stats(4);
   CS_REQUIRE(off16.p && B16.p && A16.p && c_h.p && cnt_up.p && hlist.p && pf_stat.p && pf_sums.p &&
@@ -1627,9 +1694,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     if (pblocks > 64) pblocks = 64;
     CS_HIP_CHECK(hipMemcpyAsync(off16.p, h_off16.data(), sizeof(int64_t) * (n_prob + 1),
                                 hipMemcpyHostToDevice, s));
-    CS_HIP_CHECK(hipMemsetAsync(pf_sums.p, 0, sizeof(double) * n_prob * 6, s));
-    hipLaunchKernelGGL(k_ransac_pair_sums, dim3((unsigned)std::min(pblocks, 16), (unsigned)n_prob), dim3(256), 0, s, d_probs,
-                       d_src, d_tgt, pf_sums.p);
+    hipLaunchKernelGGL(k_ransac_pair_sums, dim3((unsigned)n_prob), dim3(256), 0, s, d_probs, d_src, d_tgt, pf_sums.p);
     if (pf_nm == 2) {
       hipLaunchKernelGGL(k_ransac_pack16<2>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
                          d_probs, off16.p, d_src, d_tgt, pf_sums.p, B16.p, pf_stat.p);
@@ -1638,6 +1703,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                          d_probs, off16.p, d_src, d_tgt, pf_sums.p, B16.p, pf_stat.p);
       hipLaunchKernelGGL(k_ransac_pack16_b0, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
                          d_probs, off16.p, d_src, d_tgt, pf_sums.p, pf_stat.p, pf_tcap, B16.p);
+    }
+    if (stage2) {
+      CS_HIP_CHECK(hipMemsetAsync(pf_stat2.p, 0, sizeof(unsigned) * n_prob * PF_STAT, s));
+      CS_HIP_CHECK(hipMemsetAsync(s2_total.p, 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_ransac_pack16<2>, dim3((unsigned)pblocks, (unsigned)n_prob), dim3(256), 0, s,
+                         d_probs, off16.p, d_src, d_tgt, pf_sums.p, B32.p, pf_stat2.p);
     }
     CS_LAUNCH_CHECK();
   }
@@ -1694,6 +1765,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   struct Front {
     int it0 = 0, b = 0, par = 0;
     bool pf = false, on_side = false;
+    // placement of the round's prefilter launch (the second stage of the back half uses the same)
+    XcdTab xtab;
+    const int32_t* xcd_prob = nullptr;
+    int pslots = 1;
   };
   auto chunk_of = [&](int it0) {
     int b = it0 < first_chunk ? first_chunk : (it0 < bmax ? it0 : bmax);
@@ -1773,18 +1848,21 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         if (pf_nm == 2)
           hipLaunchKernelGGL((k_ransac_prefilter<2, false>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
                              A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
-                             (trace_it0 == it0) ? trace.p : nullptr);
+                             (trace_it0 == it0) ? trace.p : nullptr, (const int32_t*)nullptr);
         else if (pf_rtn)
           hipLaunchKernelGGL((k_ransac_prefilter<1, true>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
                              A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
-                             (trace_it0 == it0) ? trace.p : nullptr);
+                             (trace_it0 == it0) ? trace.p : nullptr, (const int32_t*)nullptr);
         else
           hipLaunchKernelGGL((k_ransac_prefilter<1, false>), dim3(nblk), dim3(256), 0, st, d_probs, off16.p, B16.p,
                              A16_r, c_h_r, it0, b, bmax, psplits, xcd_prob, xtab, pslots, ptiles, cnt_up_r,
-                             (trace_it0 == it0) ? trace.p : nullptr);
+                             (trace_it0 == it0) ? trace.p : nullptr, (const int32_t*)nullptr);
         if (trace_it0 == it0) trace_n = (size_t)nblk * 16;
       }
     }
+    f.xtab = xtab;
+    f.xcd_prob = xcd_prob;
+    f.pslots = pslots;
     if (f.on_side) (void)hipEventRecord(front_done[par].e, st);
     return f;
   };
@@ -1863,8 +1941,34 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           int fslots = surv_cap <= 256 ? 4 : 8;
           if (getenv("CS_RANSAC_FEW_SLOTS")) fslots = std::max(1, atoi(getenv("CS_RANSAC_FEW_SLOTS")));
           if (getenv("CS_RANSAC_FEW_SLICES")) fslices = std::max(1, atoi(getenv("CS_RANSAC_FEW_SLICES")));
+          const int32_t* list_p = hlist.p;
+          const int32_t* list_n = d_nsurv;
+          int list_stride = bmax;
+          const _Float16* A16_cur = A16.p + (size_t)cur.par * n_prob * bmax * PF_K;
+          const float* c_h_cur = c_h.p + (size_t)cur.par * n_prob * bmax;
+          const int s2_pslots = cur.pslots;
+          const int32_t* s2_xcd_prob = cur.xcd_prob;
+          const XcdTab& s2_xtab = cur.xtab;
+          if (stage2 && surv_cap <= PF_S2_CAP) {
+            // K = 32 bound of the survivors: rows gathered, one small prefilter launch over all pairs, list filtered again
+            hipLaunchKernelGGL(k_ransac_stage2_gather, dim3(PF_S2_CAP / 256, (unsigned)n_prob), dim3(256), 0, s, d_probs,
+                               hlist.p, d_nsurv, bmax, A16_cur, c_h_cur, pf_stat.p, pf_tcap, A16s.p, c_hs.p, cnt2.p,
+                               n_surv2.p);
+            // tiles for the WHOLE capacity: this round's survivor counts are not known on the host (surv_cap comes from the
+            // previous round and only picks kernels that are exact for any count); workgroups past a problem's list leave at once
+            const int s2tiles = std::max(1, (std::min(b, PF_S2_CAP) + PF_HYP - 1) / PF_HYP);
+            int s2splits = 8;
+            while (s2splits > 1 && m_max / s2splits < 8 * PF_ROWS) --s2splits;
+            hipLaunchKernelGGL((k_ransac_prefilter<2, false>), dim3((unsigned)(8 * s2_pslots * s2tiles * s2splits)), dim3(256), 0,
+                               s, d_probs, off16.p, B32.p, A16s.p, c_hs.p, 0, PF_S2_CAP, PF_S2_CAP, s2splits, s2_xcd_prob,
+                               s2_xtab, s2_pslots, s2tiles, cnt2.p, (unsigned long long*)nullptr, d_nsurv);
+            hipLaunchKernelGGL(k_ransac_stage2_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256), 0, s,
+                               d_probs, hlist.p, d_nsurv, bmax, cnt2.p, hlist2.p, n_surv2.p, s2_total.p);
+            list_p = hlist2.p;
+            list_n = n_surv2.p;
+          }
           hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
-                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, hlist.p, d_nsurv);
+                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, list_p, list_n, list_stride);
           err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
@@ -1946,6 +2050,13 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   }
   g_pf_stats[3] += tot_surv;
   g_pf_stats[4] += tot_eval;
+  if (stage2 && getenv("CS_RANSAC_STAGE2_STATS")) {   // diagnostics: survivors of the first / second stage of this call
+    unsigned long long h2 = 0;
+    CS_HIP_CHECK(hipMemcpyAsync(&h2, s2_total.p, sizeof(h2), hipMemcpyDeviceToHost, s));
+    CS_HIP_CHECK(hipStreamSynchronize(s));
+    fprintf(stderr, "[cs_ransac_batch] prefilter survivors: stage 1 %llu, stage 2 %llu of %llu hypotheses\n", tot_surv, h2,
+            tot_eval);
+  }
   if (check) {
     unsigned long long h_stats[4] = {0, 0, 0, 0};
     CS_HIP_CHECK(hipMemcpyAsync(h_stats, chk_stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, s));

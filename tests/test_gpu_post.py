@@ -297,6 +297,38 @@ def test_ransac_prefilter_bound_and_identity(gpu, oracle_native, monkeypatch, sc
         assert np.array_equal(exact[0][p], wT)
 
 
+def test_ransac_second_stage_leaves_the_trajectory_unchanged(gpu, monkeypatch):
+    """Round 4: the survivors of the K = 16 prefilter go through the K = 32 bound (a compact list per problem, one small
+    launch) before they are counted exactly.  With and without it (CS_RANSAC_STAGE2) the results AND the number of
+    first-stage survivors of the whole run are identical -- the survivor count is a fingerprint of every problem's best
+    count in every round: a hypothesis the second stage dropped wrongly would leave the best count lower and let more
+    through later.  Many problems of very different sizes, thresholds from tight to loose, so that the number of
+    survivors per problem and round swings from 0 to beyond the list capacity (a round's counts are not known on the host:
+    the launch must cover the whole capacity and pass what exceeds it)."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(77)
+    specs = [(int(rng.integers(300, 9000)), float(rng.choice([0.0, 0.02, 0.05, 0.15])), i) for i in range(40)]
+    probs = [_corr_problem(rng, m, f, noise=0.02, pose_id=200 + i)[:2] for m, f, i in specs]
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+    for max_corr in (0.2, 0.06, 0.02):
+        out = {}
+        for stage2 in ("0", "1"):
+            monkeypatch.setenv("CS_RANSAC_STAGE2", stage2)
+            _prefilter_stats(reset=True)
+            out[stage2] = [t.cpu().numpy() for t in B.ransac_batch(S, D, off, max_corr, 10, 60000, 0.999, 3)]
+            out[stage2].append(_prefilter_stats()[3])
+        for a, b in zip(out["0"][:4], out["1"][:4]):
+            assert np.array_equal(a, b), max_corr
+        assert out["0"][4] == out["1"][4] and out["0"][4] > 0, (max_corr, out["0"][4], out["1"][4])
+    monkeypatch.setenv("CS_RANSAC_PREFILTER", "0")
+    exact = [t.cpu().numpy() for t in B.ransac_batch(S, D, off, 0.02, 10, 60000, 0.999, 3)]
+    for a, b in zip(exact, out["1"][:4]):
+        assert np.array_equal(a, b)
+
+
 def _engine_features(gpu, cloud_ids, pose_ids):
     from corsair_amd import engine, synth
     from tests.helpers import make_batch
