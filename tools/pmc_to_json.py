@@ -16,16 +16,21 @@ if "--workload" in sys.argv:
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WIDE = ("k_ransac_prefilter", "k_knn_f16", "k_topk_f16", "k_conv_mfma", "k_conv_dma")
 DOMINANT = {"chair": "k_ransac_prefilter", "table": "k_ransac_prefilter", "stress": "k_conv_dma"}[workload]
+# the FIRST-stage prefilter instantiation (<1, true> by default); the second stage launches <2, false> on a few survivors
+DOM_MATCH = {"k_ransac_prefilter": ("k_ransac_prefilterILi1", "k_ransac_prefilter<1")}.get(DOMINANT, (DOMINANT,))
 # kernel family of bench.py's `kernel_ms` -> (kernels that belong to it, kernels of which ONE launch = one library call)
 FAMILY = {
     "conv": (("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic"), ("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic")),
-    "kmap": (("k_build_nbr", "k_row_keys", "k_sorted_tables", "k_insert", "k_emit_strided", "k_flag_first", "k_segments", "k_fill_table"), ("k_row_keys",)),
+    # one "kmap" profile scope per kernel map (its build kernel) + one per batch for the common tiling-order pass
+    "kmap": (("k_build_nbr", "k_row_keys", "k_sorted_tables", "k_insert", "k_emit_strided", "k_flag_first", "k_segments", "k_fill_table"),
+             ("k_build_nbr_lds", "k_build_nbr(", "k_row_keys")),
     "knn": (("k_knn_f16", "k_knn_rescore_f16", "k_knf_pack", "k_knn_feat"), ("k_knf_pack_queries",)),
     "chamfer": (("k_chamfer",), ("k_chamfer_mfma", "k_chamfer<")),
     "topk": (("k_topk", "k_tkf", "k_dist_matrix", "k_row_topk"), ("k_topk_finish",)),
-    "ransac_pre": (("k_ransac_prefilter",), ("k_ransac_prefilter",)),
+    "ransac_pre": (("k_ransac_prefilterILi1", "k_ransac_prefilter<1"), ("k_ransac_prefilterILi1", "k_ransac_prefilter<1")),
     "ransac_hyp": (("k_ransac_hyp<", "k_ransac_hypILi"), ("k_ransac_hyp<", "k_ransac_hypILi")),
-    "ransac_eval": (("k_ransac_count", "k_ransac_err", "k_ransac_scan", "k_ransac_survivors"), ("k_ransac_scan1",)),
+    "ransac_eval": (("k_ransac_count", "k_ransac_err", "k_ransac_scan", "k_ransac_survivors", "k_ransac_stage2",
+                     "k_ransac_prefilterILi2", "k_ransac_prefilter<2"), ("k_ransac_scan1",)),
     "symcut": (("k_symcut",), ("k_symcut_kmeans",)),
 }
 
@@ -99,7 +104,7 @@ def weighted(sel, keys):
     return n, agg
 
 
-dom = [r for r in rows if DOMINANT in r["full"]]
+dom = [r for r in rows if any(m in r["full"] for m in DOM_MATCH)]
 families = {}
 for fam, (members, anchors) in FAMILY.items():
     sel = [r for r in rows if any(m in r["full"] for m in members)]
