@@ -214,12 +214,14 @@ class Ctx:
             # The DEFAULT group is always gloo (control plane: it comes up wherever TCP does); RCCL is a second group
             # the data collectives run on.  Whether RCCL is usable is agreed on over gloo BEFORE anything depends on it
             # (no second TCPStore on MASTER_PORT + 1, no rank left blocking in an RCCL collective while its
-            # peer has already given up -- the RCCL group's own timeout is one minute).
+            # peer has already given up -- the RCCL group has its own, finite timeout).
             dist.init_process_group("gloo")
             group, err = None, None
             if self.backend == "nccl":
                 try:
-                    group = dist.new_group(backend="nccl", timeout=timedelta(seconds=60), device_id=self.dev)
+                    # (the group's timeout bounds how long a healthy rank waits in the probe for a peer whose RCCL did not
+                    # come up -- and every later collective: ranks reach the catalog all-gather within seconds of each other)
+                    group = dist.new_group(backend="nccl", timeout=timedelta(seconds=300), device_id=self.dev)
                     probe = torch.ones(1, device=self.dev)
                     dist.all_reduce(probe, group=group)     # first collective: the communicator really comes up
                     torch.cuda.synchronize()
