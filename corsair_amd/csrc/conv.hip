@@ -594,315 +594,6 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_conv_dma_p: the same kernel as PERSISTENT workgroups (round 3).  A workgroup of k_conv_dma lives 3 us in
-// its prologue (group masks, neighbour rows of the first chunks, first DMA: three dependent round trips) and
-// several us in its epilogue + the dispatch of its successor, against 17 - 50 us in the chunk loop
-// (CS_CONV_TRACE): a third of the lifetime of a 32 -> 32 tile.  Here a workgroup walks the row tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ... and the next tile is prepared under the current one:
-//   * its group masks (scalar loads) and output rows are requested when the current tile starts,
-//   * the neighbour rows of its first three chunks during the current tile's second chunk,
-//   * its first chunk is STAGED by the current tile's last chunk (which has nothing else to stage), so the
-//     stores of the epilogue are followed at once by a chunk whose data is already in LDS.
-// Inside a tile the chunk pipeline is k_conv_dma's.  Same arithmetic, same results.
-// ------------------------------------------------------------------------------------------------
-template <int RG, int CG, int NT, bool GATHER>
-__global__ __launch_bounds__(256) void k_conv_dma_p(
-    const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist, const uint32_t* __restrict__ gmask, int kvol,
-    int64_t n_out, int n_tiles, const float* __restrict__ in, int ld_in, unsigned in_bytes, int cin,
-    const float* __restrict__ w, int cout, unsigned w_bytes, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ residual, int ld_res, int relu,
-    float* __restrict__ out, int ld_out) {
-  using C = ConvDmaCfg<RG, CG, NT>;
-  constexpr int TM = C::TM, TN = C::TN;
-  static_assert(RG * CG == 4, "4 waves");
-  constexpr int A_PIECES = 4 / CG;
-  constexpr int B_PIECES = TN / 32;
-  static_assert(A_PIECES + B_PIECES <= 8, "one DMA per A-fragment step of the chunk");
-  constexpr int K_END = 32;
-  // (no residual prefetch here: 16 NT registers held through the loop cost a resident workgroup per CU, and the
-  // next tile of the workgroup hides the round trip anyway)
-  constexpr bool RES_EARLY = false;
-  __shared__ __attribute__((aligned(128))) char lds[C::LDS_BYTES];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave / CG;
-  const int cg = wave % CG;
-  const int half = lane >> 5;
-  const int rl = lane & 31;
-  const int n0 = blockIdx.y * TN;
-  const int cchunks = cin / 32;
-  const int tstride = gridDim.x;
-
-  struct Tile {
-    int32_t my_o;                  // output row of group slot rl (both lane halves)
-    unsigned mymask, kmask;        // offsets of this wave's group / of the workgroup's groups
-    unsigned a_nbr_off[A_PIECES];  // byte offset of nbr[t][0] of the tile row this lane fetches for piece i
-    bool a_row_ok[A_PIECES];
-  };
-  unsigned a_c4b[A_PIECES];
-#pragma unroll
-  for (int i = 0; i < A_PIECES; ++i) {
-    const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
-    a_c4b[i] = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-  }
-  // everything of a tile that comes from memory is REQUESTED here (plain / scalar loads) and used much later
-  auto load_tile = [&](int ti, Tile& t) {
-    const bool ok = ti < n_tiles;
-    const int64_t row0 = (int64_t)(ok ? n_tiles - 1 - ti : 0) * TM;   // heaviest tiles (end of the tiling order) first
-    const int64_t tr = row0 + rg * 32 + rl;
-    const int64_t trc = tr < n_out ? tr : 0;
-    const int32_t o = rowlist ? rowlist[trc] : (int32_t)trc;       // (unconditional load)
-    t.my_o = ok && tr < n_out ? o : -1;
-    if (GATHER) {
-      const uint32_t* gm = gmask + row0 / 32;
-      unsigned mm = gm[rg], km = gm[0];
-#pragma unroll
-      for (int g = 1; g < RG; ++g) km |= gm[g];
-      t.mymask = ok ? mm : 0u;
-      t.kmask = ok ? km : 0u;
-    } else {
-      t.mymask = ok && row0 + rg * 32 < n_out ? 1u : 0u;
-      t.kmask = ok ? 1u : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) {
-      const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
-      const int64_t q = row0 + rg * 32 + r;
-      t.a_row_ok[i] = ok && q < n_out;
-      t.a_nbr_off[i] = GATHER ? (unsigned)(q < n_out ? q : 0) * (unsigned)kvol * 4u : (unsigned)(q < n_out ? q : 0);
-    }
-  };
-  unsigned b_voff[B_PIECES];
-#pragma unroll
-  for (int j = 0; j < B_PIECES; ++j) {
-    const int f = (wave + 4 * j) * 256 + 4 * lane;
-    const int sr = f / TN;
-    b_voff[j] = (unsigned)(sr * cout + (f - sr * TN)) * 4u;
-  }
-  const i32x4 srd_a = make_srd(in, in_bytes);
-  const i32x4 srd_b = make_srd(w + n0, w_bytes - (unsigned)n0 * 4u);
-  const unsigned ld_in_b = (unsigned)ld_in * 4u;
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-  const unsigned a_lds = lds_base + rg * 4096 + cg * A_PIECES * 1024;
-  const unsigned b_lds = lds_base + C::A_BYTES + wave * 1024;
-
-  auto step = [&](unsigned kmask, int& k, int& cc) {
-    const int c1 = cc + 1;
-    const bool wrap = c1 == cchunks;
-    const unsigned rest = k < 31 ? kmask >> (k + 1) : 0u;
-    const int knext = rest ? k + 1 + __builtin_ctz(rest) : K_END;
-    cc = wrap ? 0 : c1;
-    k = k >= K_END ? K_END : (wrap ? knext : k);
-  };
-  auto fetch_src = [&](const Tile& t, int k, int32_t (&src)[A_PIECES]) {
-    const char* nbr_k = reinterpret_cast<const char*>(nbr + (k < kvol ? k : 0));
-#pragma unroll
-    for (int i = 0; i < A_PIECES; ++i)
-      src[i] = GATHER ? *reinterpret_cast<const int32_t*>(nbr_k + t.a_nbr_off[i]) : (int32_t)t.a_nbr_off[i];
-  };
-  auto a_offsets = [&](const Tile& t, const int32_t (&src)[A_PIECES], unsigned (&vo)[A_PIECES]) {
-#pragma unroll
-    for (int i = 0; i < A_PIECES; ++i)
-      vo[i] = __umul24((unsigned)src[i], ld_in_b) + a_c4b[i];   // absent = row n_in: past the descriptor's range
-  };
-  auto b_soff = [&](int k, int cc) { return (unsigned)(((k < K_END ? k : 0) * cin + cc * 32) * cout) * 4u; };
-
-  // ---- blocking start of tile `ti` (the prologue of k_conv_dma): the first tile of a workgroup, and the tile
-  // after one without any chunk (which could not stage its successor) ----
-  int ti = blockIdx.x;
-  Tile cur, nx;
-  int k = K_END, cc = 0, nk = K_END, ncc = 0, k2 = K_END, cc2 = 0;
-  unsigned vo_n[A_PIECES];
-  int32_t src2[A_PIECES];
-  int buf = 0;
-  auto start_blocking = [&]() {
-    __syncthreads();      // nobody still reads the stage the first DMA goes to
-    load_tile(ti, cur);
-    cur.mymask = __builtin_amdgcn_readfirstlane(cur.mymask);
-    cur.kmask = __builtin_amdgcn_readfirstlane(cur.kmask);
-    k = cur.kmask ? __builtin_ctz(cur.kmask) : K_END;
-    cc = 0;
-    nk = k; ncc = cc;
-    step(cur.kmask, nk, ncc);
-    k2 = nk; cc2 = ncc;
-    step(cur.kmask, k2, cc2);
-    int32_t s0[A_PIECES], s1[A_PIECES];
-    fetch_src(cur, k, s0);
-    fetch_src(cur, nk, s1);
-    fetch_src(cur, k2, src2);
-    unsigned vo0[A_PIECES];
-    a_offsets(cur, s0, vo0);
-    if (k < K_END) {
-      if ((cur.mymask >> k) & 1u) {
-#pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) buf_dma16(vo0[i], srd_a, 0u, a_lds + buf * C::STAGE_BYTES + i * 1024);
-      }
-#pragma unroll
-      for (int j = 0; j < B_PIECES; ++j)
-        buf_dma16(b_voff[j], srd_b, b_soff(k, 0), b_lds + buf * C::STAGE_BYTES + j * 4096);
-    }
-    a_offsets(cur, s1, vo_n);
-  };
-  start_blocking();
-  unsigned a_rd = lds_base + rg * 4096 + rl * 128 + (((rl >> 1) & 7) << 4) + 4 * half;
-  unsigned b_rd = lds_base + C::A_BYTES + (half * TN + cg * 32 * NT + rl) * 4;
-
-  f32x16 acc[NT];
-  while (ti < n_tiles) {
-    // ---- tile start: chunk 0 is in flight in `buf`, vo_n = row offsets of chunk 1, src2 = rows of chunk 2 ----
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    // next tile of this workgroup: request its masks and rows now
-    const bool has_nx = ti + tstride < n_tiles;
-    load_tile(ti + tstride, nx);
-    int32_t nxs0[A_PIECES], nxs1[A_PIECES], nxs2[A_PIECES];   // neighbour rows of its first three chunks
-    int nxk0 = K_END, nxk1 = K_END, nxcc1 = 0, nxk2 = K_END, nxcc2 = 0;
-#pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) nxs0[i] = nxs1[i] = nxs2[i] = -1;
-    int it = 0;
-    while (k < K_END) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      const bool active = (cur.mymask >> k) & 1u;
-      float2 av[8];   // (this lane half's two channels of the slot: see k_conv_dma)
-      float bv[16][NT];
-      auto rd = [&](int j) {
-        const float* ap = reinterpret_cast<const float*>(lds + ((a_rd ^ (unsigned)(j << 4)) - lds_base));
-        av[j].x = ap[0];
-        av[j].y = ap[2];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          bv[2 * j][t] = *reinterpret_cast<const float*>(lds + (b_rd - lds_base) + ((4 * j) * TN + t * 32) * 4);
-          bv[2 * j + 1][t] = *reinterpret_cast<const float*>(lds + (b_rd - lds_base) + ((4 * j + 2) * TN + t * 32) * 4);
-        }
-      };
-      rd(0);
-      rd(1);
-      nk = __builtin_amdgcn_readfirstlane(nk);
-      ncc = __builtin_amdgcn_readfirstlane(ncc);
-      const bool last = nk >= K_END;          // this is the tile's last chunk: it stages the NEXT TILE's first chunk
-      // first chunk of the tile: fetch the neighbour rows of the NEXT tile's first three chunks (its masks were
-      // requested when this tile started); they are consumed by this tile's last chunk and at the next tile's start
-      if (it == 0) {
-        nx.mymask = __builtin_amdgcn_readfirstlane(nx.mymask);
-        nx.kmask = __builtin_amdgcn_readfirstlane(nx.kmask);
-        nxk0 = nx.kmask ? __builtin_ctz(nx.kmask) : K_END;
-        nxk1 = nxk0; nxcc1 = 0;
-        step(nx.kmask, nxk1, nxcc1);
-        nxk2 = nxk1; nxcc2 = nxcc1;
-        step(nx.kmask, nxk2, nxcc2);
-        fetch_src(nx, nxk0, nxs0);
-        fetch_src(nx, nxk1, nxs1);
-        fetch_src(nx, nxk2, nxs2);
-      }
-      // row offsets of chunk c + 2 (or, on the last chunk, of the next tile's chunk 0) BEFORE anything else of
-      // this iteration is on the memory queue
-      unsigned vo_nn[A_PIECES];
-      a_offsets(cur, src2, vo_nn);
-      if (last) a_offsets(nx, nxs0, vo_n);
-#pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) asm volatile("" ::"v"(vo_nn[i]), "v"(vo_n[i]));
-      int k3 = k2, cc3 = cc2;
-      step(cur.kmask, k3, cc3);
-      fetch_src(cur, k3, src2);
-      // what this chunk stages: chunk c + 1 of this tile, or chunk 0 of the next tile
-      const int sk = last ? nxk0 : nk;
-      const int scc = last ? 0 : ncc;
-      const unsigned smask = last ? nx.mymask : cur.mymask;
-      const bool stage_b = sk < K_END;
-      const bool stage_a = stage_b && ((smask >> (sk & 31)) & 1u);
-      const unsigned a_dst = a_lds + (buf ^ 1) * C::STAGE_BYTES, b_dst = b_lds + (buf ^ 1) * C::STAGE_BYTES;
-      const unsigned a_so = __builtin_amdgcn_readfirstlane((unsigned)scc * 128u);
-      const unsigned b_so = __builtin_amdgcn_readfirstlane(b_soff(sk, scc));
-#pragma unroll
-      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
-      if (active) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j + 2 < 8) rd(j + 2);
-          const float a0 = av[j].x;
-          const float a1 = av[j].y;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[2 * j][t], acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[2 * j + 1][t], acc[t], 0, 0, 0);
-          if (j < A_PIECES) {
-            if (stage_a) buf_dma16(vo_n[j], srd_a, a_so, a_dst + j * 1024);
-          } else if (j < A_PIECES + B_PIECES) {
-            if (stage_b) buf_dma16(b_voff[j - A_PIECES], srd_b, b_so, b_dst + (j - A_PIECES) * 4096);
-          }
-        }
-      } else {
-        if (stage_a) {
-#pragma unroll
-          for (int i = 0; i < A_PIECES; ++i) buf_dma16(vo_n[i], srd_a, a_so, a_dst + i * 1024);
-        }
-        if (stage_b) {
-#pragma unroll
-          for (int j = 0; j < B_PIECES; ++j) buf_dma16(b_voff[j], srd_b, b_so, b_dst + j * 4096);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) vo_n[i] = vo_nn[i];
-      a_rd += buf ? -C::STAGE_BYTES : C::STAGE_BYTES;
-      b_rd += buf ? -C::STAGE_BYTES : C::STAGE_BYTES;
-      k = nk; cc = ncc;
-      nk = k2; ncc = cc2;
-      k2 = k3; cc2 = cc3;
-      buf ^= 1;
-      ++it;
-    }
-    // ---- epilogue of the tile ----
-    int32_t orow[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) orow[i] = __shfl(cur.my_o, (i & 3) + 8 * (i >> 2) + 4 * half);
-    const int64_t row0 = (int64_t)(n_tiles - 1 - ti) * TM;
-    const int32_t o_safe = rowlist ? rowlist[row0] : (int32_t)row0;
-    float res[NT][16];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = n0 + cg * 32 * NT + t * 32 + (lane & 31);
-      if (!RES_EARLY && residual) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) res[t][i] = residual[(int64_t)(orow[i] >= 0 ? orow[i] : o_safe) * ld_res + col];
-      }
-      const float sc = scale ? scale[col] : 1.f;
-      const float sh = shift ? shift[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float v = acc[t][i];
-        if (scale)
-          v = __fmaf_rn(v, sc, sh);
-        else if (shift)
-          v = v + sh;
-        if (residual) v = v + res[t][i];
-        if (relu) v = fmaxf(v, 0.0f);
-        if (orow[i] >= 0) out[(int64_t)orow[i] * ld_out + col] = v;
-      }
-    }
-    if (!has_nx) break;
-    ti += tstride;
-    if (it == 0) {        // a tile without chunks staged nothing for its successor
-      start_blocking();
-      continue;
-    }
-    // ---- the next tile becomes the current one: its chunk 0 was staged by the last chunk above ----
-    cur = nx;
-    k = nxk0; cc = 0;
-    nk = nxk1; ncc = nxcc1;
-    k2 = nxk2; cc2 = nxcc2;
-    a_offsets(cur, nxs1, vo_n);
-#pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) src2[i] = nxs2[i];
-  }
-}
-
 // Cin = 1 (the 1 -> 32 stem, model/resunet.py:49-57): a 27-term fma chain per output.  A lane first
 // gathers the <= 27 scalar inputs of ITS row (27 independent loads in flight), the wave shares them
 // through LDS and then every lane owns one output channel (its 27 weights in registers) and walks the
@@ -1084,20 +775,6 @@ __global__ void k_segmax_fin(unsigned* buf, int64_t n) {
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n = prop.multiProcessorCount;
-    else
-      n = 256;
-  }
-  return n;
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Instance normalisation (MinkowskiInstanceNorm of the IN network variants, model/common.py:23-24):
 // per sample and channel  out = (x - mean) / sqrt(var + eps) * weight + bias  with the biased variance.
@@ -1234,36 +911,8 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     hipLaunchKernelGGL((k_conv_stem<32>), dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, s, nbr, n_out, d_in,
                        ld_in, d_w, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out);
   } else if (dma_ok) {
-    // persistent workgroups (k_conv_dma_p, CS_CONV_PERSIST=1): one grid of as many workgroups as the chip holds at
-    // once, each walking row tiles b, b + G, ...
-#define CS_DMA_LAUNCH_P(RG, CG, NT, GATHER)                                                                       \
-  do {                                                                                                            \
-    static int slots = 0;                                                                                         \
-    if (!slots) {                                                                                                 \
-      int nb = 0;                                                                                                 \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_conv_dma_p<RG, CG, NT, GATHER>, 256, 0) !=          \
-              hipSuccess || nb < 1)                                                                               \
-        nb = 1;                                                                                                   \
-      slots = nb * num_cus();                                                                                     \
-    }                                                                                                             \
-    const int n_tiles = (int)ceil_div(n_out, 32 * RG);                                                            \
-    const int ny = cout / (32 * NT * CG);                                                                         \
-    int gx = slots / ny;                                                                                          \
-    if (gx < 1) gx = 1;                                                                                           \
-    if (gx > n_tiles) gx = n_tiles;                                                                               \
-    hipLaunchKernelGGL((k_conv_dma_p<RG, CG, NT, GATHER>), dim3((unsigned)gx, (unsigned)ny), dim3(256), 0, s,     \
-                       nbr_t, rowlist, gmask, kvol, n_out, n_tiles, d_in, ld_in, in_bytes, cin, d_w, cout,        \
-                       w_bytes, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out);                       \
-  } while (0)
 #define CS_DMA_LAUNCH(RG, CG, NT)                                                                              \
   do {                                                                                                          \
-    if (persist) {                                                                                              \
-      if (nbr_t)                                                                                                \
-        CS_DMA_LAUNCH_P(RG, CG, NT, true);                                                                      \
-      else                                                                                                      \
-        CS_DMA_LAUNCH_P(RG, CG, NT, false);                                                                     \
-      break;                                                                                                    \
-    }                                                                                                           \
     const dim3 grid((unsigned)ceil_div(n_out, 32 * RG), (unsigned)(cout / (32 * NT * CG)));                     \
     if (trace)                                                                                                  \
       hipLaunchKernelGGL((k_conv_dma<RG, CG, NT, true, true>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
@@ -1282,10 +931,10 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
       if (hipMalloc(&trace, trace_n * 8) != hipSuccess) trace = nullptr;
       if (trace) (void)hipMemsetAsync(trace, 0, trace_n * 8, s);
     }
-    // (measured neutral: the registers the tile prefetch holds cost the resident workgroup per CU that it was meant
-    // to make unnecessary -- 221: 72 -> 109 VGPRs; DESIGN 7c.  Off unless CS_CONV_PERSIST=1.)
+    // (a persistent-workgroup variant with next-tile prefetch, k_conv_dma_p, was measured neutral in round 3 -- the
+    // registers the prefetch holds cost the resident workgroup per CU it was meant to make unnecessary -- and was
+    // removed in round 4: HISTORY.md 7c)
     const int rev_order = !(getenv("CS_CONV_FWD_ORDER") && getenv("CS_CONV_FWD_ORDER")[0] == '1');
-    const bool persist = !trace && getenv("CS_CONV_PERSIST") && getenv("CS_CONV_PERSIST")[0] == '1';
     int cfg = dma_cfg;
     const int64_t t128 = ceil_div(n_out, 128), t64 = ceil_div(n_out, 64);
     if (cfg == 412 && cout % 64) cfg = 0;
@@ -1317,7 +966,6 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
       default: CS_DMA_LAUNCH(4, 1, 1); break;
     }
 #undef CS_DMA_LAUNCH
-#undef CS_DMA_LAUNCH_P
     if (trace) {
       std::vector<unsigned long long> h(trace_n);
       (void)hipStreamSynchronize(s);

@@ -1156,13 +1156,29 @@ __global__ __launch_bounds__(256) void k_ransac_prefilter(const RansacProb* prob
   }
 }
 
+constexpr int PF_S2_CAP = 1024;   // rows per problem of the second stage's compact list (= the largest list the few-survivor kernel takes)
+// What the second stage needs of a survivor, written by k_ransac_survivors itself when the stage runs (s2.A16s != nullptr):
+// A16s[p][slot] = A16[p][h], c_hs = c_h - beta (the K = 32 image is not centred by beta: (c - beta) in double is exact, and
+// narrowing toward -inf never tightens the test; an unusable hypothesis -- c_h = -1, zero row -- stays negative: every row
+// counts again), its counter cleared.
+struct Stage2Rows {
+  const _Float16* A16;
+  const float* c_h;
+  const unsigned* stat;
+  double tcap;
+  _Float16* A16s;
+  float* c_hs;
+  int32_t* cnt2;
+  int32_t* n_surv2;
+};
 // Survivors: hypotheses whose upper bound reaches the carried best count.  The others get count 0.
 __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const int32_t* __restrict__ cnt_up,
                                    int it0, int bcount, int bmax, int32_t* __restrict__ res_cnt,
                                    unsigned long long* __restrict__ err_by_h,
-                                   int32_t* __restrict__ hlist, int32_t* __restrict__ n_surv) {
+                                   int32_t* __restrict__ hlist, int32_t* __restrict__ n_surv, const Stage2Rows s2) {
   const int p = blockIdx.y;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h == 0 && s2.A16s) s2.n_surv2[p] = 0;
   if (h >= bcount) return;
   const RansacProb pr = probs[p];
   if (pr.done || it0 + h >= pr.est_k) return;
@@ -1171,39 +1187,22 @@ __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const i
     const int slot = atomicAdd(&n_surv[p], 1);
     hlist[(int64_t)p * bmax + slot] = h;
     err_by_h[(int64_t)p * bmax + h] = 0;  // accumulated by k_ransac_count_few
+    if (s2.A16s && slot < PF_S2_CAP) {
+      const uint4* src = reinterpret_cast<const uint4*>(s2.A16 + ((int64_t)p * bmax + h) * PF_K);
+      uint4* dst = reinterpret_cast<uint4*>(s2.A16s + ((int64_t)p * PF_S2_CAP + slot) * PF_K);
+      dst[0] = src[0];
+      dst[1] = src[1];
+      const double smax = (double)__uint_as_float(s2.stat[p * PF_STAT]);
+      const double beta = s2.tcap > 0.0 ? smax * smax : 0.0;   // the double k_ransac_hyp16 added
+      s2.c_hs[(int64_t)p * PF_S2_CAP + slot] = __double2float_rd((double)s2.c_h[(int64_t)p * bmax + h] - beta);
+      s2.cnt2[(int64_t)p * PF_S2_CAP + slot] = 0;
+    }
   }
 }
 
 // ---- second stage (round 4): the K = 16 bound leaves 3 - 4x the survivors of the K = 32 bound; the survivors of a round --
 // a compact list of ~16 hypotheses per problem -- go through the K = 32 form (a_hi . (b_hi + b_lo), same a_hi rows, same
 // eps_h) before they are counted exactly.  1.5 % of the matrix work of a first-stage launch.
-constexpr int PF_S2_CAP = 1024;   // rows per problem of the compact list (= the largest list the few-survivor kernel takes)
-// rows of the survivors, compacted: A16s[p][slot] = A16[p][hlist[p][slot]], c_hs = c_h - beta (the K = 32 image is not
-// centred by beta; the difference of two floats within a factor of two of each other is exact, and 6e-6 of eps_h covers an
-// ulp otherwise); clears the second-stage counters.  grid: (PF_S2_CAP / 256, n_prob).
-__global__ void k_ransac_stage2_gather(const RansacProb* __restrict__ probs, const int32_t* __restrict__ hlist,
-                                       const int32_t* __restrict__ n_surv, int bmax, const _Float16* __restrict__ A16,
-                                       const float* __restrict__ c_h, const unsigned* __restrict__ stat, double tcap,
-                                       _Float16* __restrict__ A16s, float* __restrict__ c_hs,
-                                       int32_t* __restrict__ cnt2, int32_t* __restrict__ n_surv2) {
-  const int p = blockIdx.y;
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot == 0) n_surv2[p] = 0;
-  if (probs[p].done) return;
-  const int n = min(n_surv[p], PF_S2_CAP);
-  if (slot >= n) return;
-  const int h = hlist[(int64_t)p * bmax + slot];
-  const uint4* src = reinterpret_cast<const uint4*>(A16 + ((int64_t)p * bmax + h) * PF_K);
-  uint4* dst = reinterpret_cast<uint4*>(A16s + ((int64_t)p * PF_S2_CAP + slot) * PF_K);
-  dst[0] = src[0];
-  dst[1] = src[1];
-  const double smax = (double)__uint_as_float(stat[p * PF_STAT]);
-  const double beta = tcap > 0.0 ? smax * smax : 0.0;   // the double k_ransac_hyp16 added
-  // (c - beta) in double is exact; narrowing toward -inf never tightens the test.  An unusable hypothesis (c_h = -1, zero
-  // row) stays negative: every row counts again
-  c_hs[(int64_t)p * PF_S2_CAP + slot] = __double2float_rd((double)c_h[(int64_t)p * bmax + h] - beta);
-  cnt2[(int64_t)p * PF_S2_CAP + slot] = 0;
-}
 // survivors of the second stage: hlist2 = the entries of hlist whose K = 32 bound still reaches the carried best count
 __global__ void k_ransac_stage2_survivors(const RansacProb* __restrict__ probs, const int32_t* __restrict__ hlist,
                                           const int32_t* __restrict__ n_surv, int bmax, const int32_t* __restrict__ cnt2,
@@ -1917,9 +1916,26 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       // SURVEY 8d unit: 30 FLOP per (hypothesis, pair) -- the work of the exact formulation the prefilter
       // stands in for (the matrix pipe executes 64 FLOP per pair: bench.py reports both)
       prof_add_units("ransac_pre", 30.0 * eval_pairs);
+      // the second stage runs when the few-survivor kernel will (decided from the previous round's counts, like the kernel
+      // choice below); its rows are written by the survivors kernel itself
+      static const int few_max = getenv("CS_RANSAC_FEW_MAX") ? std::max(atoi(getenv("CS_RANSAC_FEW_MAX")), 1) : 1024;
+      const int surv_cap = std::min(max_surv_prev, b);
+      const bool few = max_surv_prev <= few_max || b <= few_max;
+      const bool run_s2 = stage2 && few && surv_cap <= PF_S2_CAP;
+      Stage2Rows s2rows{};
+      if (run_s2) {
+        s2rows.A16 = A16.p + (size_t)cur.par * n_prob * bmax * PF_K;
+        s2rows.c_h = c_h.p + (size_t)cur.par * n_prob * bmax;
+        s2rows.stat = pf_stat.p;
+        s2rows.tcap = pf_tcap;
+        s2rows.A16s = A16s.p;
+        s2rows.c_hs = c_hs.p;
+        s2rows.cnt2 = cnt2.p;
+        s2rows.n_surv2 = n_surv2.p;
+      }
       hipLaunchKernelGGL(k_ransac_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
                          dim3(256), 0, s, d_probs, cnt_up_r, it0, b, bmax, res_cnt.p, cand_err.p, hlist.p,
-                         d_nsurv);
+                         d_nsurv, s2rows);
       // exact counts of the survivors; few hypotheses, so the pair range is split finely
       int lsplits = 16;
       while (lsplits > 1 && m_max / lsplits < RC_CHUNK) --lsplits;
@@ -1929,13 +1945,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
         // (round 3, K = 32 prefilter: 32 / 64 / 128 / 256 measured, 128 the fastest by ~1 %.  The K = 16 form of round 4
         // leaves 3 - 4x the survivors, ~16 per problem and round on the chair shape: the list kernel -- one workgroup of
         // 256 hypothesis lanes per problem -- then ran in every fourth round at 670 us)
-        static const int few_max = getenv("CS_RANSAC_FEW_MAX") ? std::max(atoi(getenv("CS_RANSAC_FEW_MAX")), 1) : 1024;
         // (the first prefiltered round has no previous count, but a chunk of b <= few_max hypotheses cannot leave more)
-        if (max_surv_prev <= few_max || b <= few_max) {
+        if (few) {
           // pair slices short enough for a thread to keep its pairs in registers across the survivors (8 per thread)
           int fslices = 8;
           while (fslices < 32 && m_max > fslices * 2048) fslices *= 2;
-          const int surv_cap = std::min(max_surv_prev, b);
           // survivor slots per (slice, problem): a workgroup loads its pairs once and walks its share of the survivors, so
           // FEW slots amortise the load (chair, same box: 2 / 4 / 8 / 16 slots -> 1 431 / 1 454 / 1 424 / 1 370 queries/s)
           int fslots = surv_cap <= 256 ? 4 : 8;
@@ -1944,16 +1958,12 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           const int32_t* list_p = hlist.p;
           const int32_t* list_n = d_nsurv;
           int list_stride = bmax;
-          const _Float16* A16_cur = A16.p + (size_t)cur.par * n_prob * bmax * PF_K;
-          const float* c_h_cur = c_h.p + (size_t)cur.par * n_prob * bmax;
           const int s2_pslots = cur.pslots;
           const int32_t* s2_xcd_prob = cur.xcd_prob;
           const XcdTab& s2_xtab = cur.xtab;
-          if (stage2 && surv_cap <= PF_S2_CAP) {
-            // K = 32 bound of the survivors: rows gathered, one small prefilter launch over all pairs, list filtered again
-            hipLaunchKernelGGL(k_ransac_stage2_gather, dim3(PF_S2_CAP / 256, (unsigned)n_prob), dim3(256), 0, s, d_probs,
-                               hlist.p, d_nsurv, bmax, A16_cur, c_h_cur, pf_stat.p, pf_tcap, A16s.p, c_hs.p, cnt2.p,
-                               n_surv2.p);
+          if (run_s2) {
+            // K = 32 bound of the survivors (rows compacted by k_ransac_survivors): one small prefilter launch over all
+            // pairs, then the list filtered again
             // tiles for the WHOLE capacity: this round's survivor counts are not known on the host (surv_cap comes from the
             // previous round and only picks kernels that are exact for any count); workgroups past a problem's list leave at once
             const int s2tiles = std::max(1, (std::min(b, PF_S2_CAP) + PF_HYP - 1) / PF_HYP);

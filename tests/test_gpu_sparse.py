@@ -66,7 +66,7 @@ def test_conv_bit_exact(gpu, oracle_native, cin, cout):
     assert got.shape == (n, cout) and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("cfg", ["411", "412", "414", "221", "222", "141", "old", "persist", "persist411", "front"])
+@pytest.mark.parametrize("cfg", ["411", "412", "414", "221", "222", "141", "old", "front"])
 def test_conv_every_tile_shape_bit_exact(gpu, oracle_native, monkeypatch, cfg):
     """Every tile shape of the LDS-DMA kernel (CS_CONV_CFG=<row groups><column groups><32-column
     accumulators per wave>; shapes a layer's Cout does not allow fall back to the default choice) and
@@ -80,10 +80,6 @@ def test_conv_every_tile_shape_bit_exact(gpu, oracle_native, monkeypatch, cfg):
         monkeypatch.setenv("CS_CONV_DMA", "0")
     elif cfg == "front":                     # tiles taken from the front of the tiling order (default: from the end)
         monkeypatch.setenv("CS_CONV_FWD_ORDER", "1")
-    elif cfg.startswith("persist"):          # persistent workgroups with next-tile prefetch (k_conv_dma_p)
-        monkeypatch.setenv("CS_CONV_PERSIST", "1")
-        if cfg != "persist":
-            monkeypatch.setenv("CS_CONV_CFG", cfg[7:])
     else:
         monkeypatch.setenv("CS_CONV_CFG", cfg)
     coords, feats, _, _ = make_batch([5, 6, 7], n_points=5000)
