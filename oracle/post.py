@@ -88,7 +88,11 @@ def draw_anchors(n, n_anchor, rng_key, rng_counter):
     return gen.choice(n, n_anchor, replace=False).astype(np.int32)
 
 
-def gate_and_order(centers, counts, min_cdist, max_err, n, K, force=False):
+GATE_REFERENCE = (0.15, 0.15)          # utils/symmetry.py:232-257: dist.min() > 0.15 > max(error)
+GATE_ANY = (0.0, float("inf"))         # any finite model passes (bench.py, random-init weights; corsair_amd/registration.py)
+
+
+def gate_and_order(centers, counts, min_cdist, max_err, n, K, gate=GATE_REFERENCE):
     """The acceptance gate and centre ordering of symmetric_cut4 (utils/symmetry.py:232-257):
     accept anchors with dist.min() > 0.15 > max(error), keep the one with the smallest std of label
     fractions (first on ties); K=4: order = [0, nearest, farthest, middle] by distance from centre 0.
@@ -96,9 +100,7 @@ def gate_and_order(centers, counts, min_cdist, max_err, n, K, force=False):
     counts = np.asarray(counts, np.float64)[:, :K]
     ratios = counts / float(n)
     std = np.sqrt(np.var(ratios, axis=1))
-    valid = (min_cdist > 0.15) & (0.15 > max_err) & (std < 100)
-    if force:  # bench-only (see bench.py): accept the best-balanced anchor whatever the gate says
-        valid = np.isfinite(max_err) & (min_cdist > 0)
+    valid = (min_cdist > gate[0]) & (gate[1] > max_err) & (std < 100)
     if not valid.any():
         raise AttributeError("'NoneType' object has no attribute 'cluster_centers_'")
     std_m = np.where(valid, std, np.inf)
@@ -115,7 +117,7 @@ def gate_and_order(centers, counts, min_cdist, max_err, n, K, force=False):
 def symmetric_cut4(feat, raw_pc, K, anchors, n_nn=50, n_init=10, max_iter=300, seed=0, force_gate=False):
     """Returns the integer part label of every voxel (part p == reference mask p)."""
     centers, counts, mcd, mer = native.symcut_fit(feat, raw_pc, anchors, K, n_nn, n_init, max_iter, seed)
-    sel = gate_and_order(centers, counts, mcd, mer, len(raw_pc), K, force_gate)
+    sel = gate_and_order(centers, counts, mcd, mer, len(raw_pc), K, GATE_ANY if force_gate else GATE_REFERENCE)
     return native.symcut_labels(raw_pc, K, sel)
 
 

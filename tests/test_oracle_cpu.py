@@ -493,10 +493,10 @@ def test_sym_pose_host_logic_part_configs():
     Ks = [2, 4, 4, 2, 4, 2, 4, 4, 2]
     n = [int(N[p].sum(1).max()) for p in range(P)]
     cand = [0, 1, 2, 4, 5, 6, 8]
-    for force in (False, True):
-        sel, ok = R.gate_and_order_batch(C, N, MCD, MER, n, Ks, cand, force)
+    for gate in (R.GATE_REFERENCE, R.GATE_ANY, (0.1, 0.3)):
+        sel, ok = R.gate_and_order_batch(C, N, MCD, MER, n, Ks, cand, gate)
         for p in range(P):
-            one = R.gate_and_order(C[p], N[p], MCD[p], MER[p], n[p], Ks[p], force) if p in cand else None
+            one = R.gate_and_order(C[p], N[p], MCD[p], MER[p], n[p], Ks[p], gate) if p in cand else None
             assert ok[p] == (one is not None)
             if one is not None:
                 assert np.array_equal(sel[p], one)
