@@ -47,8 +47,8 @@ BATCH = 32
 # the full 32-query C1 shape on the CPU port (`--cpu-sample 32 --cpu-problems 100000`), measured once per round
 # on a GPU box's host cores and printed next to the bounded sample of every run
 FULL_SHAPE_CPU = {
-    "chair": {"value": 0.152, "unit": "queries/s", "cores": 16, "seconds": 210.5, "date": "round 2", "commit": "d39958b",
-              "file": "profiles/r2l_chair_cpu32_line.json"},
+    "chair": {"value": 0.171, "unit": "queries/s", "cores": 16, "seconds": 187.5, "date": "round 4", "commit": "f255a11",
+              "file": "profiles/r4t_chair_cpu32_line.json"},
 }
 
 # label -> count; table: histogram of the reference's configs/04379243_scan2cad_rot_sym_label.txt
@@ -546,7 +546,7 @@ class StrongEvalWorkload:
 
         res = sharding.run_eval_sharded(self.pipe, self.ctx.dist, self.ctx.rank, self.ctx.world, self.catalog, self.queries,
                                         self.best_match, self.table, np.stack(self.q_T), self.lib_T, self.sym, self.kind,
-                                        True, None, True)
+                                        True, None, True, None, 3)   # three registration batches in flight per rank
         self.results.append((b, res))
 
     def same_results(self, a, b):

@@ -225,7 +225,7 @@ def _report(ransac, sym, rate):
 
 
 def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, category="chair",
-             register_top1=True, cache_dir=None, ignore_cache=False, force_gate=False, batch_size=None):
+             register_top1=True, cache_dir=None, ignore_cache=False, force_gate=False, batch_size=None, in_flight=1):
     """The reference's evaluation, end to end (evaluation.py:207-441), on the MI355X path.
 
     catalog / queries: lists of [n,3] clouds (already normalised; f32 catalog clouds as CADLib loads them,
@@ -238,7 +238,7 @@ def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, cat
          eval_pose of both estimates (evaluation.py:297-331) -- batched, not one Python iteration each;
          skipped when the nine cache files exist (evaluation.py:287, _load_data),
       4. aggregation + the log block (evaluation.py:334-383), 5. the result cache (evaluation.py:421-441).
-    Returns an EvalResult."""
+    in_flight: registration batches in flight (host threads x HIP streams; identical results).  Returns an EvalResult."""
     from . import cache as C_
 
     cfg = pipe.cfg
@@ -254,7 +254,7 @@ def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, cat
     from_cache = per_query is not None
     if per_query is None:
         pos_idx = np.asarray(stat["top1_predict" if register_top1 else "gt"], dtype=np.int64)
-        per_query = register_queries(pipe, qs, np.arange(Q), cat, pos_idx, syms, base_T, lib_T, force_gate, bs)
+        per_query = register_queries(pipe, qs, np.arange(Q), cat, pos_idx, syms, base_T, lib_T, force_gate, bs, in_flight)
         if cache_dir is not None:
             C_.save_results(cache_dir, category, register_top1, per_query)
     return finish_eval(stat, per_query, from_cache)
@@ -271,18 +271,25 @@ def retrieval_stat(pipe, q_desc, lib_desc, best_match, table):
     return retrieval.scan2cad_retrieval_eval_rank(rank, table, best_match, pos_n)
 
 
-def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, force_gate=False, batch_size=None):
+def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, force_gate=False, batch_size=None,
+                     in_flight=1):
     """The registration loop of evaluation.py:297-331 over the embedded queries `qs`, whose GLOBAL query numbers are
     `query_ids` (they seed the anchor draws, so a query gives the same result whichever rank or batch it lands in):
     sym_pose against CAD pos_idx[q] and eval_pose of both estimates, batched.  Returns the nine arrays of
-    evaluation.py:421-441 (cache.NAMES) for these queries, in the order of `query_ids`."""
+    evaluation.py:421-441 (cache.NAMES) for these queries, in the order of `query_ids`.
+    in_flight > 1: that many batches at a time, each on its own host thread and HIP stream (batches are independent;
+    the library's scratch cache is per thread and stream-ordered) -- same results, the host work of one batch hides
+    behind the kernels of the others (bench.py's `batches_in_flight`)."""
     from . import cache as C_
 
     bs = batch_size or pipe.cfg.batch_size
     query_ids = np.asarray(query_ids, dtype=np.int64)
-    out = {k: [] for k in C_.NAMES}
-    for s in range(0, len(query_ids), bs):
-        loc = np.arange(s, min(len(query_ids), s + bs))
+    if not len(query_ids):
+        return {k: np.zeros((0, 4, 4), np.float32) if k.startswith("Ts_est") else
+                np.zeros(0, bool if k == "sym_ransac_success" else np.float64) for k in C_.NAMES}
+    batches = [np.arange(s, min(len(query_ids), s + bs)) for s in range(0, len(query_ids), bs)]
+
+    def one(loc):
         ids = query_ids[loc]
         q = qs.gather(loc)
         cads = cat.gather(pos_idx[ids])
@@ -294,14 +301,34 @@ def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, for
         T1 = [lib_T[j] for j in pos_idx[ids]]
         t_r, r_r = pose_losses(Tr, T0, T1, cad_sym)
         t_s, r_s = pose_losses(Tb, T0, T1, cad_sym)
-        for k, v in (("Ts_est_ransac", Tr), ("Ts_est_best", Tb), ("t_losses_ransac", t_r),
-                     ("t_losses_sym", t_s), ("r_losses_ransac", r_r), ("r_losses_sym", r_s),
-                     ("sym_ransac_success", res.ok), ("chamfer_dist_ransac", cdr), ("chamfer_dist_sym", cdb)):
-            out[k].append(np.asarray(v))
-    if not len(query_ids):
-        return {k: np.zeros((0, 4, 4), np.float32) if k.startswith("Ts_est") else
-                np.zeros(0, bool if k == "sym_ransac_success" else np.float64) for k in C_.NAMES}
-    return {k: np.concatenate(v) for k, v in out.items()}
+        return {"Ts_est_ransac": Tr, "Ts_est_best": Tb, "t_losses_ransac": t_r, "t_losses_sym": t_s,
+                "r_losses_ransac": r_r, "r_losses_sym": r_s, "sym_ransac_success": np.asarray(res.ok),
+                "chamfer_dist_ransac": cdr, "chamfer_dist_sym": cdb}
+
+    depth = min(int(in_flight), len(batches))
+    on_gpu = torch.device(getattr(pipe, "device", "cpu")).type == "cuda"
+    if depth <= 1 or not on_gpu:
+        done = [one(loc) for loc in batches]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        dev = torch.device(pipe.device)
+        torch.cuda.synchronize(dev)          # the embedded sets were made on the caller's stream
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        done = [None] * len(batches)
+
+        def work(w):
+            if dev.index is not None:
+                torch.cuda.set_device(dev.index)
+            with torch.cuda.stream(streams[w]):
+                for i in range(w, len(batches), depth):
+                    done[i] = one(batches[i])
+                streams[w].synchronize()
+
+        with ThreadPoolExecutor(max_workers=depth, thread_name_prefix="corsair-register") as ex:
+            for f in [ex.submit(work, w) for w in range(depth)]:
+                f.result()               # surfaces worker failures
+    return {k: np.concatenate([np.asarray(d[k]) for d in done]) for k in C_.NAMES}
 
 
 def finish_eval(stat, per_query, from_cache):
@@ -424,6 +451,7 @@ def build_parser():
     ap.add_argument("--n-points", type=int, default=10000)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--ransac-max-iter", type=int, default=100000)
+    ap.add_argument("--in-flight", type=int, default=3, help="registration batches in flight (host threads x HIP streams)")
     ap.add_argument("--device", default="cuda", choices=["cuda"], help="there is no CPU path")
     return ap
 
@@ -461,7 +489,7 @@ def main(argv=None):
         raise SystemExit(f"shape mismatch: table {table.shape}, best_match {len(best_match)}, lib poses {len(lib_T)} "
                          f"for C = {C}, Q = {Q}")
     res = run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, a.category, a.register_top1,
-                   a.cache_dir, a.ignore_cache, False, a.batch_size)
+                   a.cache_dir, a.ignore_cache, False, a.batch_size, a.in_flight)
     print(f"category: {a.category}")
     print(f"precision: {res.stat['precision']}\ntop1_error: {res.stat['top1_error']}")
     print(res.report)

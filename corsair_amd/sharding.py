@@ -200,7 +200,7 @@ def embed_catalog_sharded(pipe, dist, rank, world, catalog, batch_size=None):
 
 
 def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, table, base_T, lib_T, syms, category="chair",
-                     register_top1=True, cache_dir=None, force_gate=False, batch_size=None):
+                     register_top1=True, cache_dir=None, force_gate=False, batch_size=None, in_flight=1):
     """harness.run_eval on `world` ranks (one process per GPU), strong scaling: ONE evaluation of all Q queries.
 
       1. catalog clouds dealt to the ranks by voxel count, embedded, ONE all-gather of the embedded catalog
@@ -218,7 +218,7 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
 
     if dist is None or world == 1:
         return H.run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, category, register_top1,
-                          cache_dir, True, force_gate, batch_size)
+                          cache_dir, True, force_gate, batch_size, in_flight)
     cfg = pipe.cfg
     bs = batch_size or cfg.batch_size
     dev = pipe.device
@@ -238,7 +238,7 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
     stat = H.retrieval_stat(pipe, desc_all, cat.desc, best_match, table)
     # 3. registration of the own queries
     pos_idx = np.asarray(stat["top1_predict" if register_top1 else "gt"], dtype=np.int64)
-    local = H.register_queries(pipe, qs, mine, cat, pos_idx, syms, base_T, lib_T, force_gate, bs)
+    local = H.register_queries(pipe, qs, mine, cat, pos_idx, syms, base_T, lib_T, force_gate, bs, in_flight)
     # 4. one result set, query order
     per_query = {}
     for name in C_.NAMES:

@@ -80,3 +80,22 @@ def test_run_eval_registers_against_gt_when_asked(gpu, small_eval):
                            lib_T[:16], syms[:16], "chair", False, force_gate=True)
     assert len(res.per_query["r_losses_sym"]) == 8 and not res.from_cache
     assert np.isfinite(res.per_query["chamfer_dist_sym"]).all()
+
+
+def test_run_eval_with_batches_in_flight_equals_the_sequential_loop(gpu, small_eval):
+    """register_queries(in_flight=3): three registration batches at a time on three host threads / HIP streams (what
+    `python -m corsair_amd.harness` and `bench.py --scaling strong` use) -- the nine per-query arrays equal the sequential
+    loop's bit for bit, whatever the batch size (here 5: seven batches, the last one ragged)."""
+    from corsair_amd import cache, harness
+
+    pipe, data, table = small_eval
+    catalog, queries, best_match, base_T, lib_T, syms = data.eval_inputs()
+    cat = pipe.embed_clouds(catalog)
+    qs = pipe.embed_clouds(queries)
+    seq = harness.run_eval(pipe, cat, qs, best_match, table, base_T, lib_T, syms, "chair", True, force_gate=True,
+                           batch_size=5)
+    par = harness.run_eval(pipe, cat, qs, best_match, table, base_T, lib_T, syms, "chair", True, force_gate=True,
+                           batch_size=5, in_flight=3)
+    assert seq.stat == par.stat and seq.report == par.report
+    for k in cache.NAMES:
+        assert seq.per_query[k].dtype == par.per_query[k].dtype and np.array_equal(seq.per_query[k], par.per_query[k]), k
