@@ -7,13 +7,17 @@
 // problem is reproducible anywhere.  Iterations are processed in growing chunks (256, 256, 512, ...,
 // 16 384); within a chunk
 //   k_ransac_hyp        one lane per hypothesis: sample ransac_n pairs (packed 32-B rows), closed-form
-//                       rigid fit (Horn quaternion, 4x4 Jacobi eigen-solver, f64), emit R|t as f64
+//                       rigid fit (Horn quaternion; largest eigenpair of the 4x4 matrix from its characteristic
+//                       polynomial, horn_qcp, with the Jacobi eigen-solver as per-lane fallback; f64), emit R|t as f64
 //                       (Open3D keeps the Matrix4d; the f32 cast happens at the very end, where the
 //                       reference casts the result: utils/symmetry.py:274)
 //   k_ransac_prefilter  (from iteration 256 on) an UPPER bound of every hypothesis' inlier count on the
 //                       f16 matrix cores; hypotheses whose bound is below the carried best cannot
-//                       matter and get count 0.  ~0.02 % survive.  See the block comment above the
-//                       kernel and DESIGN.md ("RANSAC prefilter") for the bound.
+//                       matter and get count 0.  Round 4: <1, true> = one MFMA per tile (K = 16: a_hi . b_hi',
+//                       the dropped term bounded per pair), signs counted by v_add_f32 under
+//                       round-toward-minus-infinity; 0.2 % survive, and the survivors go through the K = 32
+//                       bound (<2, false> in list mode) before the exact count.  See the block comments above
+//                       k_ransac_pack16_b0 / the kernel and DESIGN.md ("RANSAC prefilter") for the bound.
 //   k_ransac_count      the exact count in Open3D's arithmetic: the reference hands Open3D f64 points
 //                       (utils/eval_pose.py:83-86) and Eigen transforms and compares in double, so the
 //                       inlier test is evaluated in f64: a lane owns one hypothesis (R|t in 12 f64
@@ -1236,6 +1240,20 @@ __global__ void k_ransac_check_bound(const RansacProb* __restrict__ probs, const
   atomicAdd(&stats[2], (unsigned long long)(u - e > 0 ? u - e : 0));
 }
 
+// Debug check of the SECOND stage (CS_RANSAC_CHECK=1): the K = 32 bound of every compacted survivor must dominate its exact
+// count too (violations and comparisons go to the same counters as the first stage's).
+__global__ void k_ransac_check_bound2(const RansacProb* __restrict__ probs, const int32_t* __restrict__ exact,
+                                      const int32_t* __restrict__ hlist, const int32_t* __restrict__ n_surv, int bmax,
+                                      const int32_t* __restrict__ cnt2, unsigned long long* __restrict__ stats) {
+  const int p = blockIdx.y;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (probs[p].done || slot >= min(n_surv[p], PF_S2_CAP)) return;
+  const int e = exact[(int64_t)p * bmax + hlist[(int64_t)p * bmax + slot]], u = cnt2[(int64_t)p * PF_S2_CAP + slot];
+  if (e > u) atomicAdd(&stats[0], 1ULL);
+  atomicAdd(&stats[1], 1ULL);
+  atomicAdd(&stats[2], (unsigned long long)(u - e > 0 ? u - e : 0));
+}
+
 // Exact counts (and fixed-point errors) when only a handful of hypotheses survive the prefilter (the
 // normal case: ~2 per problem and round).  The MFMA list kernel above needs a 128-hypothesis tile per
 // workgroup and costs ~110 us per round even for two survivors.  Here the pair range of a problem is
@@ -1995,6 +2013,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
                            exact_dbg.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
         hipLaunchKernelGGL(k_ransac_check_bound, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob),
                            dim3(256), 0, s, d_probs, exact_dbg.p, cnt_up_r, it0, b, bmax, chk_stats.p);
+        if (run_s2)
+          hipLaunchKernelGGL(k_ransac_check_bound2, dim3(PF_S2_CAP / 256, (unsigned)n_prob), dim3(256), 0, s, d_probs,
+                             exact_dbg.p, hlist.p, d_nsurv, bmax, cnt2.p, chk_stats.p);
       }
     }
     static const hipError_t scan1_lds = hipFuncSetAttribute(
