@@ -749,19 +749,28 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
           d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bop[g][2], d, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            if (d[r] < thr_eff[g]) {
+            // one compare + one scalar branch per value while no lane of the wave has a hit (three of four values
+            // once a few hundred targets have been seen); the pending-list push only runs behind it
+#ifdef KNF_NOHIT
+            const bool hit = d[r] < thr_eff[g] - 1.0e30f;
+#else
+            const bool hit = d[r] < thr_eff[g];
+#endif
+            if (__any(hit)) {
+              if (hit) {
 #pragma unroll
-              for (int e = KNF_PEND - 1; e > 0; --e) {
-                pd[g][e] = pd[g][e - 1];
-                pi[g][e] = pi[g][e - 1];
+                for (int e = KNF_PEND - 1; e > 0; --e) {
+                  pd[g][e] = pd[g][e - 1];
+                  pi[g][e] = pi[g][e - 1];
+                }
+                pd[g][0] = d[r];
+                pi[g][0] = ti_s[buf][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                ++pn[g];
               }
-              pd[g][0] = d[r];
-              pi[g][0] = ti_s[buf][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-              ++pn[g];
-            }
-            if (__any(pn[g] == KNF_PEND)) {
-              rank_pending(g);
-              thr_eff[g] = (!use_labels || want[g] == lab) ? thr[g] : -INFINITY;
+              if (__any(pn[g] == KNF_PEND)) {
+                rank_pending(g);
+                thr_eff[g] = (!use_labels || want[g] == lab) ? thr[g] : -INFINITY;
+              }
             }
           }
         }
