@@ -45,6 +45,7 @@ def _declare(lib):
         "cs_kernelmap_free": (None, [vp]),
         "cs_conv_fwd": (c_int, [vp, c_int64, c_int64, vp, c_int, c_int, vp, c_int, vp, vp, vp,
                                 c_int, c_int, vp, c_int, vp]),
+        "cs_conv_split_reset": (c_int, []),
         "cs_affine_act": (c_int, [c_int64, c_int, vp, c_int, vp, vp, vp, c_int, c_int, vp, c_int, vp]),
         "cs_row_l2_normalize": (c_int, [c_int64, c_int, vp, c_int, c_float, vp, c_int, vp]),
         "cs_segmented_max": (c_int, [c_int64, c_int, vp, c_int, vp, c_int, c_int, vp, vp]),

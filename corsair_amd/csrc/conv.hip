@@ -23,6 +23,9 @@
 //   * epilogue (BN affine / bias, residual add, ReLU) is applied to the accumulators and written
 //     with an arbitrary leading dimension so decoder outputs land directly in the concat buffer.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 #include <algorithm>
@@ -594,6 +597,253 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT, off by default (CS_CONV_SPLIT=3 or 2; SURVEY 8d: "bf16 only behind a parity-checked flag"):
+// the same convolutions on the bf16 matrix cores.  The exact chain above runs on the SIMD's f32 vector ALU (157 TF peak);
+// v_mfma_f32_32x32x16_bf16 is a true matrix-core instruction (16x the rate), so every f32 operand is cut into NS bf16
+// pieces (truncation: a = hi + mid + lo EXACTLY for NS = 3, every piece 8 significant bits) and the products whose
+// weight is above 2^-24 are accumulated in f32: NS = 3 keeps hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi (6 MFMAs per 16
+// channels, dropped terms <= 2^-23 |a||b|), NS = 2 keeps hi.hi, hi.lo, lo.hi (3 MFMAs, ~2^-16 |a||b|).  NOT bit-identical
+// to the oracle's fma chain (other summation order, other rounding): the default path and every parity test stay on
+// k_conv_dma; tools/conv_split_report.py reports speed and the feature / ranking differences of this path.
+//   * input rows: the same gathered f32 row image as k_conv_dma (LDS-DMA through a buffer descriptor, swizzled slots);
+//     a lane reads ITS 8 channels of a 16-channel step (two ds_read_b128) and cuts them in registers: v_perm_b32 packs the
+//     high halves of two values, v_and + v_sub give the exact remainder -- 5.5 VALU instructions per value for NS = 3.
+//   * weights: cut once per layer (k_split_weights, cached by pointer) into fragment order
+//     [offset][32-channel chunk][piece][step][lane half][cout][8 x bf16]: a B fragment is one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <int NS>
+__global__ void k_split_weights(const float* __restrict__ w, int kvol, int cin, int cout, uint16_t* __restrict__ wq) {
+  // one thread per (offset, channel, cout)
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)kvol * cin * cout;
+  if (i >= total) return;
+  const int col = (int)(i % cout);
+  const int ci = (int)((i / cout) % cin);
+  const int k = (int)(i / ((int64_t)cout * cin));
+  const int cc = ci >> 5, s = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
+  float r = w[i];
+  const int64_t chunk = ((int64_t)k * (cin >> 5) + cc) * (NS * 4);
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    unsigned bits;
+    if (pl == NS - 1 && NS == 2) {
+      // last piece of the two-piece form: round to nearest even instead of cutting
+      const unsigned u = __float_as_uint(r);
+      bits = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    } else {
+      bits = __float_as_uint(r) >> 16;
+    }
+    r = r - __uint_as_float(bits << 16);
+    const int seg = (pl * 2 + s) * 2 + h;
+    wq[((chunk + seg) * cout + col) * 8 + e] = (uint16_t)bits;
+  }
+}
+
+template <int RG, int CG, int NT, int NS, bool GATHER>
+__global__ __launch_bounds__(256) void k_conv_split(
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist, const uint32_t* __restrict__ gmask, int kvol,
+    int64_t n_out, const float* __restrict__ in, int ld_in, unsigned in_bytes, int cin, const uint16_t* __restrict__ wq, int cout,
+    unsigned wq_bytes, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, int ld_res, int relu, float* __restrict__ out, int ld_out, int rev_order, int dbg) {
+  constexpr int TM = 32 * RG, TN = 32 * NT * CG;
+  static_assert(RG * CG == 4, "4 waves");
+  constexpr int A_PIECES = 4 / CG;
+  constexpr int SEGS = NS * 4;
+  constexpr int A_BYTES = TM * 128, B_BYTES = SEGS * TN * 16, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NPB = B_BYTES / 1024;      // 1-KiB DMA instructions per weight stage
+  constexpr int B_PIECES = (NPB + 3) / 4;
+  constexpr int K_END = 32;
+  __shared__ __attribute__((aligned(128))) char lds[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave / CG;
+  const int cg = wave % CG;
+  const int half = lane >> 5;
+  const int rl = lane & 31;
+  const int64_t row0 = (int64_t)(rev_order ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * TM;
+  const int n0 = blockIdx.y * TN;
+  const int cchunks = cin / 32;
+
+  int32_t my_o = -1;
+  {
+    const int64_t t = row0 + rg * 32 + rl;
+    if (t < n_out) my_o = rowlist ? rowlist[t] : (int32_t)t;
+  }
+  unsigned mymask, kmask;
+  if (GATHER) {
+    const uint32_t* gm = gmask + row0 / 32;
+    mymask = gm[rg];
+    kmask = gm[0];
+#pragma unroll
+    for (int g = 1; g < RG; ++g) kmask |= gm[g];
+  } else {
+    mymask = row0 + rg * 32 < n_out ? 1u : 0u;
+    kmask = 1u;
+  }
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  kmask = __builtin_amdgcn_readfirstlane(kmask);
+
+  unsigned a_nbr_off[A_PIECES];
+  unsigned a_c4b[A_PIECES];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
+    const int64_t t = row0 + rg * 32 + r;
+    a_nbr_off[i] = GATHER ? (unsigned)(t < n_out ? t : 0) * (unsigned)kvol * 4u : (unsigned)(t < n_out ? t : 0);
+    a_c4b[i] = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+  }
+  // weight stage = [SEGS][TN][16 B], linear in 16-B units u = piece * 64 + lane: segment u / TN, column u % TN
+  unsigned b_voff[B_PIECES];
+#pragma unroll
+  for (int j = 0; j < B_PIECES; ++j) {
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int seg = u / TN, col = u - seg * TN;
+    b_voff[j] = (unsigned)(seg * cout + col) * 16u;
+  }
+  const i32x4 srd_a = make_srd(in, in_bytes);
+  const i32x4 srd_b = make_srd(wq + (size_t)n0 * 8, wq_bytes - (unsigned)n0 * 16u);
+  const unsigned ld_in_b = (unsigned)ld_in * 4u;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  const unsigned a_lds = lds_base + rg * 4096 + cg * A_PIECES * 1024;
+  const unsigned b_lds = lds_base + A_BYTES + wave * 1024;
+
+  auto step = [&](int& k, int& cc) {
+    const int c1 = cc + 1;
+    const bool wrap = c1 == cchunks;
+    const unsigned rest = k < 31 ? kmask >> (k + 1) : 0u;
+    const int knext = rest ? k + 1 + __builtin_ctz(rest) : K_END;
+    cc = wrap ? 0 : c1;
+    k = k >= K_END ? K_END : (wrap ? knext : k);
+  };
+  auto fetch_src = [&](int k, int32_t (&src)[A_PIECES]) {
+    const char* nbr_k = reinterpret_cast<const char*>(nbr + (k < kvol ? k : 0));
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i)
+      src[i] = GATHER ? *reinterpret_cast<const int32_t*>(nbr_k + a_nbr_off[i]) : (int32_t)a_nbr_off[i];
+  };
+  auto stage = [&](int k, int cc, const int32_t (&src)[A_PIECES], int b) {
+    const unsigned a_so = __builtin_amdgcn_readfirstlane((unsigned)cc * 128u);
+    const unsigned b_so = __builtin_amdgcn_readfirstlane((unsigned)((k * cchunks + cc) * SEGS) * (unsigned)cout * 16u);
+    if ((mymask >> k) & 1u) {
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i)
+        buf_dma16(__umul24((unsigned)src[i], ld_in_b) + a_c4b[i], srd_a, a_so, a_lds + b * STAGE_BYTES + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j)
+      if (wave + 4 * j < NPB) buf_dma16(b_voff[j], srd_b, b_so, b_lds + b * STAGE_BYTES + j * 4096);
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  int32_t orow[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) orow[i] = __shfl(my_o, (i & 3) + 8 * (i >> 2) + 4 * half);
+
+  int k = kmask ? __builtin_ctz(kmask) : K_END, cc = 0;
+  int nk = k, ncc = cc;
+  step(nk, ncc);
+  int32_t src_n[A_PIECES];   // neighbour rows of the chunk staged next
+  if (k < K_END) {
+    int32_t s0[A_PIECES];
+    fetch_src(k, s0);
+    fetch_src(nk, src_n);
+    stage(k, 0, s0, 0);
+  }
+  // slot of channel block q (4 channels) of row rl: q ^ ((rl >> 1) & 7); this lane reads blocks 4 s + 2 half + {0, 1}
+  const unsigned a_rd0 = rg * 4096 + rl * 128 + ((((rl >> 1) & 7) ^ (2 * half)) << 4);
+  const unsigned b_rd0 = A_BYTES + (half * TN + cg * 32 * NT + rl) * 16;
+  int buf = 0;
+  while (k < K_END) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool active = (mymask >> k) & 1u;
+    if (nk < K_END && !(dbg & 1)) stage(nk, ncc, src_n, buf ^ 1);
+    int k2 = nk, cc2 = ncc;
+    step(k2, cc2);
+    fetch_src(k2, src_n);   // waited for by the vmcnt(0) of the next iteration, used by its stage()
+    if (active && !(dbg & 2)) {
+      const char* sb = lds + buf * STAGE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sb + (a_rd0 ^ (unsigned)((4 * s) << 4)));
+        const float4 v1 = *reinterpret_cast<const float4*>(sb + (a_rd0 ^ (unsigned)((4 * s + 1) << 4)));
+        float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        union {
+          unsigned u[4];
+          bf16x8 v;
+        } ap[NS];
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const unsigned x = __float_as_uint(r[2 * e2]), y = __float_as_uint(r[2 * e2 + 1]);
+            if (pl == NS - 1 && NS == 2) {
+              unsigned pk;
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(r[2 * e2]), "v"(r[2 * e2 + 1]));
+              ap[pl].u[e2] = pk;
+            } else {
+              ap[pl].u[e2] = __builtin_amdgcn_perm(y, x, 0x07060302u);
+              if (pl + 1 < NS) {
+                r[2 * e2] = r[2 * e2] - __uint_as_float(x & 0xffff0000u);
+                r[2 * e2 + 1] = r[2 * e2 + 1] - __uint_as_float(y & 0xffff0000u);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          bf16x8 bp[NS];
+#pragma unroll
+          for (int pl = 0; pl < NS; ++pl)
+            bp[pl] = *reinterpret_cast<const bf16x8*>(sb + b_rd0 + ((pl * 2 + s) * 2 * TN + t * 32) * 16);
+          // smallest products first
+#pragma unroll
+          for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa <= sum; ++pa) {
+              const int pb = sum - pa;
+              if (pa < NS && pb < NS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[pa].v, bp[pb], acc[t], 0, 0, 0);
+            }
+        }
+      }
+    }
+    k = nk;
+    cc = ncc;
+    nk = k2;
+    ncc = cc2;
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + cg * 32 * NT + t * 32 + (lane & 31);
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = shift ? shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (orow[i] < 0) continue;
+      float v = acc[t][i];
+      if (scale)
+        v = __fmaf_rn(v, sc, sh);
+      else if (shift)
+        v = v + sh;
+      if (residual) v = v + residual[(int64_t)orow[i] * ld_res + col];
+      if (relu) v = fmaxf(v, 0.0f);
+      out[(int64_t)orow[i] * ld_out + col] = v;
+    }
+  }
+}
+
 // Cin = 1 (the 1 -> 32 stem, model/resunet.py:49-57): a 27-term fma chain per output.  A lane first
 // gathers the <= 27 scalar inputs of ITS row (27 independent loads in flight), the wave shares them
 // through LDS and then every lane owns one output channel (its 27 weights in registers) and walks the
@@ -857,6 +1107,18 @@ __global__ void k_inorm_apply(const float* __restrict__ x, int ld_in, int c, int
 
 using namespace cs;
 
+namespace {
+struct SplitKey {
+  const float* w;
+  int kvol, cin, cout, ns;
+  bool operator<(const SplitKey& o) const {
+    return std::tie(w, kvol, cin, cout, ns) < std::tie(o.w, o.kvol, o.cin, o.cout, o.ns);
+  }
+};
+std::mutex g_split_mu;
+std::map<SplitKey, uint16_t*> g_split_w;   // pieces of a layer's weights (experiment; never freed: a handful of MB)
+}  // namespace
+
 extern "C" {
 
 int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float* d_in, int ld_in,
@@ -907,9 +1169,74 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
                       w_bytes64 < (1LL << 31) && n_in < (1LL << 24) && (int64_t)ld_in * 4 < (1LL << 24) &&
                       n_out * (int64_t)kvol * 4 < (1LL << 32);
   const unsigned in_bytes = (unsigned)in_bytes64, w_bytes = (unsigned)w_bytes64;
+  // CS_CONV_SPLIT=3 / 2: the bf16-piece experiment (k_conv_split), read per call so that a report can switch it
+  const int split_ns = getenv("CS_CONV_SPLIT") ? atoi(getenv("CS_CONV_SPLIT")) : 0;
+  CS_REQUIRE(split_ns == 0 || split_ns == 2 || split_ns == 3, CS_ERR_INVALID, "cs_conv_fwd: CS_CONV_SPLIT must be 2 or 3");
   if (cin == 1 && cout == 32 && kvol == 27 && nbr && n_in >= 1 && dma_on) {
     hipLaunchKernelGGL((k_conv_stem<32>), dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, s, nbr, n_out, d_in,
                        ld_in, d_w, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out);
+  } else if (dma_ok && split_ns && nbr_t) {   // (1x1 layers stay on the exact kernel: measured slower in pieces)
+    // experiment (see k_conv_split): bf16 matrix cores, weights cut once per layer and kept by pointer
+    const uint16_t* wq = nullptr;
+    const size_t wq_bytes64 = (size_t)kvol * cin * cout * split_ns * 2;
+    CS_REQUIRE(wq_bytes64 < (1ULL << 31), CS_ERR_INVALID, "cs_conv_fwd: split weights too large");
+    const int64_t w_total = (int64_t)kvol * cin * cout;
+    auto cut = [&](uint16_t* buf) {
+      if (split_ns == 3)
+        hipLaunchKernelGGL(k_split_weights<3>, dim3((unsigned)ceil_div(w_total, 256)), dim3(256), 0, s, d_w, kvol, cin, cout, buf);
+      else
+        hipLaunchKernelGGL(k_split_weights<2>, dim3((unsigned)ceil_div(w_total, 256)), dim3(256), 0, s, d_w, kvol, cin, cout, buf);
+    };
+    // default: the weights are cut on every call into stream-ordered scratch (~10 us).  CS_CONV_SPLIT_CACHE=1 keeps the
+    // pieces per weight POINTER for the life of the process -- only valid while the caller keeps those weights alive
+    // and unchanged (an engine's parameters; tools/conv_split_report.py) -- cs_conv_split_reset() drops them.
+    PoolBuf<uint16_t> wq_scratch;
+    if (getenv("CS_CONV_SPLIT_CACHE") && getenv("CS_CONV_SPLIT_CACHE")[0] == '1') {
+      std::lock_guard<std::mutex> lock(g_split_mu);
+      SplitKey key{d_w, kvol, cin, cout, split_ns};
+      auto it = g_split_w.find(key);
+      if (it == g_split_w.end()) {
+        uint16_t* buf = nullptr;
+        CS_HIP_CHECK(hipMalloc(&buf, wq_bytes64));
+        cut(buf);
+        CS_LAUNCH_CHECK();
+        CS_HIP_CHECK(hipStreamSynchronize(s));   // other streams may use the cached pieces right away
+        it = g_split_w.emplace(key, buf).first;
+      }
+      wq = it->second;
+    } else {
+      pool_use_stream(s);
+      CS_REQUIRE(wq_scratch.alloc(wq_bytes64 / 2), CS_ERR_HIP, "cs_conv_fwd: out of memory for the split weights");
+      cut(wq_scratch.p);
+      CS_LAUNCH_CHECK();
+      wq = wq_scratch.p;
+    }
+    const int rev_order = 1;
+    const int sdbg = getenv("CS_CONV_SPLIT_DBG") ? atoi(getenv("CS_CONV_SPLIT_DBG")) : 0;   // timing probes only (wrong results)
+    int cfg = getenv("CS_CONV_SPLIT_CFG") ? atoi(getenv("CS_CONV_SPLIT_CFG")) : 0;
+    if ((cfg == 412 || cfg == 221) && cout % 64) cfg = 0;
+    if ((cfg == 222 || cfg == 141) && cout % 128) cfg = 0;
+    // the tile shapes of the exact kernel (CS_CONV_SPLIT_CFG sweep on the stress batch, three pieces, whole forward: these
+    // 5.1 - 5.2 ms, 2x2x1 everywhere 4.9 - 5.1, 4x1x2 6.4, 4x1x1 6.6; exact chain 6.0: profiles/r4e_conv_split_cfg_sweep.txt)
+    if (!cfg) cfg = cout % 128 == 0 ? 141 : (cout % 64 == 0 ? 221 : 411);
+#define CS_SPLIT_LAUNCH(RG, CG, NT)                                                                            \
+  do {                                                                                                          \
+    const dim3 grid((unsigned)ceil_div(n_out, 32 * RG), (unsigned)(cout / (32 * NT * CG)));                     \
+    if (split_ns == 3)                                                                                          \
+      hipLaunchKernelGGL((k_conv_split<RG, CG, NT, 3, true>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
+                         ld_in, in_bytes, cin, wq, cout, (unsigned)wq_bytes64, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, rev_order, sdbg); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_conv_split<RG, CG, NT, 2, true>), grid, dim3(256), 0, s, nbr_t, rowlist, gmask, kvol, n_out, d_in, \
+                         ld_in, in_bytes, cin, wq, cout, (unsigned)wq_bytes64, d_scale, d_shift, d_residual, ld_res, relu, d_out, ld_out, rev_order, sdbg); \
+  } while (0)
+    switch (cfg) {
+      case 412: CS_SPLIT_LAUNCH(4, 1, 2); break;
+      case 221: CS_SPLIT_LAUNCH(2, 2, 1); break;
+      case 222: CS_SPLIT_LAUNCH(2, 2, 2); break;
+      case 141: CS_SPLIT_LAUNCH(1, 4, 1); break;
+      default: CS_SPLIT_LAUNCH(4, 1, 1); break;
+    }
+#undef CS_SPLIT_LAUNCH
   } else if (dma_ok) {
 #define CS_DMA_LAUNCH(RG, CG, NT)                                                                              \
   do {                                                                                                          \
@@ -1024,6 +1351,13 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
                        ld_res, relu, d_out, ld_out);
   }
   CS_LAUNCH_CHECK();
+  return CS_OK;
+}
+
+int cs_conv_split_reset(void) {
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  for (auto& kv : g_split_w) (void)hipFree(kv.second);
+  g_split_w.clear();
   return CS_OK;
 }
 

@@ -111,6 +111,14 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
                 const float* d_residual, int ld_res, int relu, float* d_out, int ld_out,
                 void* stream);
 
+/* EXPERIMENT, off by default (reduced precision "only behind a parity-checked flag").  With the environment
+ * variable CS_CONV_SPLIT=3 (or 2) cs_conv_fwd evaluates the layers the LDS-DMA kernel serves on the bf16 matrix cores:
+ * every f32 operand cut into 3 (2) bf16 pieces, 6 (3) products per 16 channels accumulated in f32 -- NOT the fma chain
+ * above, not bit-identical to the reference's ME kernels; tests/test_gpu_sparse.py bounds the drift, and
+ * tools/conv_split_report.py reports speed and ranking differences.  CS_CONV_SPLIT_CACHE=1 keeps a layer's cut weights
+ * per weight pointer (valid while the caller keeps the weights alive and unchanged); this call drops them. */
+int cs_conv_split_reset(void);
+
 /* Eval-mode batch-norm / bias / residual / ReLU as a stand-alone op (for the unfused, op-by-op
  * MinkowskiEngine-compatible path): same epilogue formula as cs_conv_fwd applied to d_in. */
 int cs_affine_act(int64_t n, int c, const float* d_in, int ld_in, const float* d_scale,

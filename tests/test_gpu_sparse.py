@@ -194,3 +194,45 @@ def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, sym):
     _, okm2 = oref.build_maps(shuffled)
     for name in ("s1", "s1_s2", "s2_s1_T"):
         assert np.array_equal(getattr(m2, name).table().cpu().numpy(), okm2[name]), name
+
+
+@pytest.mark.parametrize("ns,cfg", [(3, "0"), (3, "411"), (3, "412"), (3, "221"), (3, "222"), (3, "141"), (2, "0")])
+def test_conv_split_experiment_close_to_exact_chain(gpu, oracle_native, monkeypatch, ns, cfg):
+    """CS_CONV_SPLIT=3 / 2 (off by default): the bf16-piece kernel on the matrix cores.  It is NOT
+    bit-identical to the oracle's fma chain and no parity claim rests on it; this test pins how far it may drift:
+    per output |diff| <= tol * sum_k |x||w| (the scale of one output's terms) with tol = 2^-19 for three pieces (kept
+    products cover everything above 2^-23 |a||b|) and 2^-13 for two -- every tile shape, gathered / strided / transposed maps, ragged last tile, epilogue."""
+    from corsair_amd import backend as B
+    from oracle import resunet as oref
+
+    coords, _, _, _ = make_batch([3, 4], n_points=3000)
+    m = _maps(gpu, coords)
+    _, okm = oref.build_maps(coords)
+    tol = 2.0 ** -19 if ns == 3 else 2.0 ** -13
+    for cin, cout in [(32, 32), (64, 128), (128, 64), (256, 128)]:
+        rng = np.random.default_rng(cin * 1000 + cout)
+        n = coords.shape[0]
+        x = rng.standard_normal((n, cin)).astype(np.float32)
+        w = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((n, cout)).astype(np.float32)
+        xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+        args = (torch.from_numpy(scale).to(gpu), torch.from_numpy(shift).to(gpu), torch.from_numpy(res).to(gpu), True)
+        n2 = m.c2.n
+        x2 = torch.from_numpy(rng.standard_normal((n2, cin)).astype(np.float32)).to(gpu)
+        cases = [(m.s1, xd, args), (m.s1_s2, xd, ()), (m.s2_s1_T, x2, ())]   # (1x1 layers stay on the exact kernel)
+        exact = [B.conv_fwd(km, xi, wd if km is not None else wd[13], *a).cpu().numpy() for km, xi, a in cases]
+        # magnitude of an output's terms: the same convolution of |x| with |w| (exact path, no epilogue)
+        mag = [B.conv_fwd(km, xi.abs(), (wd if km is not None else wd[13]).abs()).cpu().numpy() for km, xi, a in cases]
+        monkeypatch.setenv("CS_CONV_SPLIT", str(ns))
+        monkeypatch.setenv("CS_CONV_SPLIT_CFG", cfg)
+        got = [B.conv_fwd(km, xi, wd if km is not None else wd[13], *a).cpu().numpy() for km, xi, a in cases]
+        monkeypatch.delenv("CS_CONV_SPLIT")
+        monkeypatch.delenv("CS_CONV_SPLIT_CFG")
+        for i, (g, e, mg) in enumerate(zip(got, exact, mag)):
+            bound = tol * (mg * (1.5 if i == 0 else 1.0) + 1e-6)
+            assert g.shape == e.shape
+            worst = float((np.abs(g - e) / bound).max())
+            assert worst <= 1.0, f"cin {cin} cout {cout} case {i}: diff / bound = {worst}"
+        assert any(not np.array_equal(g, e) for g, e in zip(got, exact))   # the experiment really ran
