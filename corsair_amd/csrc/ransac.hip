@@ -257,6 +257,11 @@ __device__ __forceinline__ int xcd_problem(const int32_t* __restrict__ xcd_ptr, 
   return xcd_ptr ? xcd_ptr[i] : tab.v[i];
 }
 
+// (defined with the prefilter's operand kernels below)
+__device__ __forceinline__ void pf_emit_row(const RansacProb& pr, int p, int h, int bmax, const double (&R)[3][3], double (&t)[3],
+                                            const unsigned* __restrict__ stat, const double* __restrict__ sums, double thr2,
+                                            double tcap, _Float16* __restrict__ A16, float* __restrict__ c_h);
+
 template <int RN>
 __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     const float4* __restrict__ pair32, int it0,
@@ -264,7 +269,11 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
                                                     uint64_t seed,
                                                     const int32_t* __restrict__ xcd_prob, const XcdTab xcd_tab,
                                                     int slots, int tiles, int force_jacobi,
-                                                    double* __restrict__ hyp) {
+                                                    double* __restrict__ hyp,
+                                                    // fused prefilter rows (A16 != nullptr): what k_ransac_hyp16 computes
+                                                    const unsigned* __restrict__ pf_stat, const double* __restrict__ pf_sums,
+                                                    double thr2, double tcap, _Float16* __restrict__ A16,
+                                                    float* __restrict__ c_h, int32_t* __restrict__ cnt_zero) {
   // 1-D grid dealt round-robin to the XCDs: XCD x samples only the problems xcd_prob[x][.], whose
   // correspondences then stay in that XCD's L2 (the sampling is a random gather of 24-B rows)
   const int xcd = blockIdx.x & 7;
@@ -274,6 +283,8 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
   if (p < 0) return;
   const int h = (item - slot * tiles) * blockDim.x + threadIdx.x;
   if (h >= bcount) return;
+  // the prefilter behind this kernel adds the partial counts of its pair-range splits with atomics: cleared here
+  if (cnt_zero) cnt_zero[(int64_t)p * bmax + h] = 0;
   const RansacProb pr = prob_view(probs, p);
   const int itr = it0 + h;
   if (pr.done || itr >= pr.est_k) return;
@@ -391,14 +402,17 @@ __global__ __launch_bounds__(256) void k_ransac_hyp(const RansacProb* probs,
   R[2][1] = 2.0 * (qy * qz + qw * qx);
   R[2][2] = 1.0 - 2.0 * (qx * qx + qy * qy);
   double* o = hyp + ((int64_t)p * 12) * bmax + h;
+  double tv[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double t = ct_[a] - (R[a][0] * cs_[0] + R[a][1] * cs_[1] + R[a][2] * cs_[2]);
+    tv[a] = t;
     o[(int64_t)(4 * a + 0) * bmax] = R[a][0];
     o[(int64_t)(4 * a + 1) * bmax] = R[a][1];
     o[(int64_t)(4 * a + 2) * bmax] = R[a][2];
     o[(int64_t)(4 * a + 3) * bmax] = t;
   }
+  if (A16) pf_emit_row(pr, p, h, bmax, R, tv, pf_stat, pf_sums, thr2, tcap, A16, c_h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,26 +771,12 @@ __global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __re
 //   * |R s|^2 = |s|^2 only up to the orthonormality defect E = R^T R - I:    <= 3 max|E| smax^2
 // with W <= (2 smax + |t|)^2.  A hypothesis outside the f16 range (or not finite) gets c_h = -inf and
 // a zero row: every pair counts, it always survives to the exact kernel.
-__global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
-                               const unsigned* __restrict__ stat, const double* __restrict__ sums, int it0, int bcount,
-                               int bmax, double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
-                               int32_t* __restrict__ cnt_zero, double tcap) {
-  const int p = blockIdx.y;
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= bcount) return;
-  // the prefilter behind this kernel adds the partial counts of its pair-range splits with atomics: the
-  // counters of this round are cleared here (a hipMemset2DAsync per round before)
-  if (cnt_zero) cnt_zero[(int64_t)p * bmax + h] = 0;
-  const RansacProb pr = prob_view(probs, p);
-  if (pr.done || it0 + h >= pr.est_k) return;
-  const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
-  double R[3][3], t[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b) R[a][b] = hp[(int64_t)(4 * a + b) * bmax];
-    t[a] = hp[(int64_t)(4 * a + 3) * bmax];
-  }
+// Prefilter row of one hypothesis (R, t): 16 f16 coefficients + the f32 constant c_h (see k_ransac_prefilter).  Called by
+// k_ransac_hyp16 (hypotheses read back from the table) and, fused, by k_ransac_hyp itself (round 4: one launch and one
+// 96-byte read per hypothesis less).
+__device__ __forceinline__ void pf_emit_row(const RansacProb& pr, int p, int h, int bmax, const double (&R)[3][3], double (&t)[3],
+                                            const unsigned* __restrict__ stat, const double* __restrict__ sums, double thr2,
+                                            double tcap, _Float16* __restrict__ A16, float* __restrict__ c_h) {
   // the pair image is in centred coordinates: t' = t + R mu_s - mu_q (see k_ransac_pair_sums); the f64 rounding of these
   // nine operations (<= 1e-15 (|t| + |mu|)) sits far inside the 6e-6 of eps
   {
@@ -834,6 +834,29 @@ __global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict
   // unusable: a zero row and c_h = -1, so every row (padding included) counts and the hypothesis survives.  (FINITE: the
   // round-toward-minus-infinity counters of k_ransac_prefilter<1, true> add the results themselves.)
   c_h[(int64_t)p * bmax + h] = usable ? __double2float_rd((tt + beta) - (thr2 + eps)) : -1.0f;
+}
+
+__global__ void k_ransac_hyp16(const RansacProb* probs, const double* __restrict__ hyp,
+                               const unsigned* __restrict__ stat, const double* __restrict__ sums, int it0, int bcount,
+                               int bmax, double thr2, _Float16* __restrict__ A16, float* __restrict__ c_h,
+                               int32_t* __restrict__ cnt_zero, double tcap) {
+  const int p = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= bcount) return;
+  // the prefilter behind this kernel adds the partial counts of its pair-range splits with atomics: the
+  // counters of this round are cleared here (a hipMemset2DAsync per round before)
+  if (cnt_zero) cnt_zero[(int64_t)p * bmax + h] = 0;
+  const RansacProb pr = prob_view(probs, p);
+  if (pr.done || it0 + h >= pr.est_k) return;
+  const double* hp = hyp + ((int64_t)p * 12) * bmax + h;
+  double R[3][3], t[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[a][b] = hp[(int64_t)(4 * a + b) * bmax];
+    t[a] = hp[(int64_t)(4 * a + 3) * bmax];
+  }
+  pf_emit_row(pr, p, h, bmax, R, t, stat, sums, thr2, tcap, A16, c_h);
 }
 
 // Upper bounds of the inlier counts.
@@ -1831,30 +1854,39 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       (void)hipMemcpyAsync(xcd_prob, tab.data(), sizeof(int32_t) * 8 * pslots, hipMemcpyHostToDevice, sh);
     }
     double* hyp_r = hyp.p + (size_t)par * n_prob * 12 * bmax;
+    _Float16* A16_r = f.pf ? A16.p + (size_t)par * n_prob * bmax * PF_K : nullptr;
+    float* c_h_r = f.pf ? c_h.p + (size_t)par * n_prob * bmax : nullptr;
+    int32_t* cnt_up_r = f.pf ? cnt_up.p + (size_t)par * n_prob * bmax : nullptr;
+    const int ptiles = (b + PF_HYP - 1) / PF_HYP;
+    // 1024 workgroups are resident (4 per CU): split the pair range until there are >= 8 rounds of
+    // workgroups, as long as a workgroup keeps >= 8 stages
+    int psplits = (int)((8 * 1024 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
+    if (psplits < 1) psplits = 1;
+    if (psplits > 16) psplits = 16;
+    while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
+    // the prefilter rows of the hypotheses come out of the hypothesis kernel itself (CS_RANSAC_FUSE_HYP16=0: a second
+    // kernel reads the table back, the arrangement of rounds 1 - 3)
+    static const bool fuse16 = !(getenv("CS_RANSAC_FUSE_HYP16") && getenv("CS_RANSAC_FUSE_HYP16")[0] == '0');
+    const bool fused = f.pf && fuse16;
     {
       ProfScope prof("ransac_hyp", sh);
       const int htiles = (b + 255) / 256;
+      _Float16* fa = fused ? A16_r : nullptr;
+      int32_t* fz = fused && psplits > 1 ? cnt_up_r : nullptr;
       if (ransac_n == 10)
         hipLaunchKernelGGL(k_ransac_hyp<10>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r,
+                           pf_stat.p, pf_sums.p, thr2, pf_tcap, fa, c_h_r, fz);
       else
         hipLaunchKernelGGL(k_ransac_hyp<0>, dim3((unsigned)(8 * pslots * htiles)), dim3(256), 0, sh, d_probs,
-                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r);
+                           pair32.p, it0, b, bmax, ransac_n, seed, xcd_prob, xtab, pslots, htiles, force_jacobi, hyp_r,
+                           pf_stat.p, pf_sums.p, thr2, pf_tcap, fa, c_h_r, fz);
     }
     if (f.pf) {
-      _Float16* A16_r = A16.p + (size_t)par * n_prob * bmax * PF_K;
-      float* c_h_r = c_h.p + (size_t)par * n_prob * bmax;
-      int32_t* cnt_up_r = cnt_up.p + (size_t)par * n_prob * bmax;
-      const int ptiles = (b + PF_HYP - 1) / PF_HYP;
-      // 1024 workgroups are resident (4 per CU): split the pair range until there are >= 8 rounds of
-      // workgroups, as long as a workgroup keeps >= 8 stages
-      int psplits = (int)((8 * 1024 + (int64_t)live * ptiles - 1) / std::max<int64_t>((int64_t)live * ptiles, 1));
-      if (psplits < 1) psplits = 1;
-      if (psplits > 16) psplits = 16;
-      while (psplits > 1 && m_max / psplits < 8 * PF_ROWS) --psplits;
-      hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
-                         0, sh, d_probs, hyp_r, pf_stat.p, pf_sums.p, it0, b, bmax, thr2, A16_r, c_h_r,
-                         psplits > 1 ? cnt_up_r : (int32_t*)nullptr, pf_tcap);
+      if (!fused)
+        hipLaunchKernelGGL(k_ransac_hyp16, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256),
+                           0, sh, d_probs, hyp_r, pf_stat.p, pf_sums.p, it0, b, bmax, thr2, A16_r, c_h_r,
+                           psplits > 1 ? cnt_up_r : (int32_t*)nullptr, pf_tcap);
       if (sh != st) {   // the prefilter (side stream) follows the hypotheses (third stream)
         (void)hipEventRecord(hyp_done[par].e, sh);
         (void)hipStreamWaitEvent(st, hyp_done[par].e, 0);
