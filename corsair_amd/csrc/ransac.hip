@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
 // The pair side is split into f16 hi + lo, the hypothesis side is rounded to f16 (a_hi): a_hi . b_hi +
 // a_hi . b_lo (K = 32) is two v_mfma_f32_32x32x16_f16 per 32 x 32 tile (16x the f32 matrix rate) whose
 // accumulator INPUT holds |t|^2 - (thr^2 + eps_h): the sign of the result says whether the pair is
-// within the INFLATED threshold.  eps_h bounds |d~^2 - d^2| (k_ransac_hyp16) -- including the dropped
+// within the INFLATED threshold.  eps_h bounds |d~^2 - d^2| (pf_emit_row) -- including the dropped
 // (a - a_hi) . b, bounded per hypothesis with the per-problem maxima of |b_k| -- so the sign count is an
 // UPPER bound of the exact inlier count.  Hypotheses whose bound is below the carried best get count
 // 0, the few survivors go through the exact f64 kernels: results are unchanged bit for bit.
@@ -588,7 +588,7 @@ __host__ __device__ static inline int64_t pf_padded(int64_t m) { return (m + PF_
 // float bit patterns (non-negative floats order like their bits), rounded up.
 // grid: x = blocks over the rows of a problem (grid-stride), y = problem; off16[p] = first row.
 // Per-problem sums of the source and target points (mu = sum / m is evaluated with the same expression by every consumer).  The prefilter works in coordinates CENTRED per problem, s' = s - mu_s, q' = q - mu_q: the residual is the same,
-// R s' + t' - q' = R s + t - q with t' = t + R mu_s - mu_q (k_ransac_hyp16), but every magnitude the error bounds scale with
+// R s' + t' - q' = R s + t - q with t' = t + R mu_s - mu_q (pf_emit_row), but every magnitude the error bounds scale with
 // -- smax, W, |t'| = |c'_t - R c'_s| with c' the centroids of the ten sampled points in centred coordinates -- shrinks to the
 // spread of the problem's points.  The part-to-part problems of split_corr (utils/symmetry.py:145-179: a leg against a leg)
 // sit far from the origin; without the centring 30 % of their hypotheses exceeded the |t| cap of the K = 16 form.
@@ -704,8 +704,8 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 // K = 16 form, second pass over the pairs (needs the problem's smax, which the first pass produces): the constant term of
 // every pair becomes   b_0' = round_down_f16( b_0 - E_p ),   E_p = (1 + 2^-10) sum_{k=1..15} A_k |b_k - hi(b_k)|,
 // with A_k an upper bound of |a_hi_k| over all USABLE hypotheses of the problem:
-//   k = 4..12  (a = -2 R):          |a| <= 2 sqrt(1 + max|E|) <= 2.002   (k_ransac_hyp16 requires max|E| < 1e-3)
-//   k = 1..3, 13..15 (2 R^T t, -2 t): |a| <= 2 |t| sqrt(1 + max|E|) with |t| <= tcap * smax: k_ransac_hyp16 CHECKS that and
+//   k = 4..12  (a = -2 R):          |a| <= 2 sqrt(1 + max|E|) <= 2.002   (pf_emit_row requires max|E| < 1e-3)
+//   k = 1..3, 13..15 (2 R^T t, -2 t): |a| <= 2 |t| sqrt(1 + max|E|) with |t| <= tcap * smax: pf_emit_row CHECKS that and
 //     marks the other hypotheses unusable (they survive to the exact kernels).  |t| = |c_t - R c_s| can reach 2 smax, but
 //     both centroids are means of ten points of a centred object: on the bench clouds |t| / smax has median 0.2 and
 //     99.99 % of the hypotheses are below 0.8, so tcap = 0.75 (CS_RANSAC_PF_TCAP) costs 1e-4 of them and shrinks E_p 2.7x
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void k_ransac_pack16(const RansacProb* __restr
 // hypothesis side adds beta to its accumulator input.  f16 is finer near zero: the round-down costs ~6e-5 instead of 2.4e-4.
 // and |a_hi| <= |a| (1 + 2^-11).  Then  sum_k a_hi_k b'_k  <=  sum_k a_hi_k (b_hi_k + b_lo_k)  for every usable hypothesis:
 // the one-MFMA value is never above what the K = 32 form computes exactly, i.e. every pair the K = 32 form counts is
-// counted -- the count stays an UPPER bound (k_ransac_hyp16's eps_h covers the rest as before).  The price is a looser
+// counted -- the count stays an UPPER bound (pf_emit_row's eps_h covers the rest as before).  The price is a looser
 // bound: E_p is ~1e-3 for unit-sized objects (2.5 % of thr^2 = 0.04), the rounding of b_0 another ~2.4e-4 on average.
 __global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __restrict__ probs,
                                                           const int64_t* __restrict__ off16,
@@ -1220,7 +1220,7 @@ __global__ void k_ransac_survivors(const RansacProb* __restrict__ probs, const i
       dst[0] = src[0];
       dst[1] = src[1];
       const double smax = (double)__uint_as_float(s2.stat[p * PF_STAT]);
-      const double beta = s2.tcap > 0.0 ? smax * smax : 0.0;   // the double k_ransac_hyp16 added
+      const double beta = s2.tcap > 0.0 ? smax * smax : 0.0;   // the double pf_emit_row added
       s2.c_hs[(int64_t)p * PF_S2_CAP + slot] = __double2float_rd((double)s2.c_h[(int64_t)p * bmax + h] - beta);
       s2.cnt2[(int64_t)p * PF_S2_CAP + slot] = 0;
     }
