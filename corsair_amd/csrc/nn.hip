@@ -580,7 +580,6 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
   constexpr int STAGE_KIB = STAGE_BYTES / 1024;
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
   __shared__ __attribute__((aligned(16))) float tn_s[2][KNF_ROWS];
-  __shared__ int32_t ti_s[2][KNF_ROWS];
   __shared__ int32_t wrange[2][4];
   const KnnWork wk = work[blockIdx.x];
   const int tid = threadIdx.x;
@@ -696,27 +695,21 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
         if (piece < STAGE_KIB) lds_dma16(gp + piece * 1024, lds_base + b * STAGE_BYTES + piece * 1024);
       }
     };
-    auto load_rows = [&](int base, float& tn, int32_t& ti) {   // unconditional (clamped) loads
+    auto load_rows = [&](int base, float& tn) {   // unconditional (clamped) loads
       int r = base + (tid % KNF_ROWS);
       r = r > t_hi - 1 ? t_hi - 1 : r;
       r = r < t_lo ? t_lo : r;
       tn = tn32[wk.t0 + r];
-      ti = ti32[wk.t0 + r];
     };
-    auto store_rows = [&](int b, int base, float tn, int32_t ti) {
-      if (tid < KNF_ROWS) {  // rows past the label's range can never be hit
-        const bool ok = base + tid < t_hi;
-        tn_s[b][tid] = ok ? tn : INFINITY;
-        ti_s[b][tid] = ok ? ti : 0x7fffffff;
-      }
+    auto store_rows = [&](int b, int base, float tn) {
+      if (tid < KNF_ROWS) tn_s[b][tid] = base + tid < t_hi ? tn : INFINITY;  // rows past the label's range can never be hit
     };
     __syncthreads();  // the previous label pass may still read the buffers
     {
       float tn0;
-      int32_t ti0;
-      load_rows(t_lo, tn0, ti0);
+      load_rows(t_lo, tn0);
       issue_dma(0, t_lo);
-      store_rows(0, t_lo, tn0, ti0);
+      store_rows(0, t_lo, tn0);
     }
     int buf = 0;
     for (int base = t_lo; base < t_hi; base += KNF_ROWS) {
@@ -724,14 +717,14 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
       __syncthreads();
       const bool more = base + KNF_ROWS < t_hi;
       float tn_next;
-      int32_t ti_next;
-      load_rows(base + KNF_ROWS, tn_next, ti_next);
+      load_rows(base + KNF_ROWS, tn_next);
       if (more) issue_dma(buf ^ 1, base + KNF_ROWS);
 #pragma unroll 1
       for (int t = 0; t < KNF_ROWS / 32; ++t) {
         if (base + 32 * t >= t_hi) break;  // whole tile past the range (block-uniform)
         const _Float16* arow =
             reinterpret_cast<const _Float16*>(lds + buf * STAGE_BYTES) + (t * 32 + col) * KNF_PITCH + 8 * half;
+        const int32_t tile_pos = base + 32 * t + 4 * half;
         f16x8 a[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const f16x8*>(arow + 16 * m);
@@ -764,7 +757,7 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
                   pi[g][e] = pi[g][e - 1];
                 }
                 pd[g][0] = d[r];
-                pi[g][0] = ti_s[buf][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                pi[g][0] = tile_pos + ((r & 3) + 8 * (r >> 2));   // position in the image; its row id is looked up at the end
                 ++pn[g];
               }
               if (__any(pn[g] == KNF_PEND)) {
@@ -775,7 +768,7 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
           }
         }
       }
-      if (more) store_rows(buf ^ 1, base + KNF_ROWS, tn_next, ti_next);
+      if (more) store_rows(buf ^ 1, base + KNF_ROWS, tn_next);
       buf ^= 1;
     }
   }
@@ -785,8 +778,9 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
     const int qloc = wave * 32 * KNF_NG + 32 * g + col;
     if (qvalid[g]) {
       const int64_t base = ((wk.o0 + qloc) * 2 + half) * KNF_KK;
+      // shortlist entries are positions in the target image (no LDS read on the hit path): row ids only now
 #pragma unroll
-      for (int j = 0; j < KNF_KK; ++j) cand_i[base + j] = bi[g][j];
+      for (int j = 0; j < KNF_KK; ++j) cand_i[base + j] = bi[g][j] != 0x7fffffff ? ti32[wk.t0 + bi[g][j]] : 0x7fffffff;
       if (half == 0) cand_tau[wk.o0 + qloc] = thr[g];
     }
   }
