@@ -362,6 +362,29 @@ def test_symcut_fit_bit_exact(gpu, oracle_native):
         assert np.array_equal(lab, oracle_native.symcut_labels(x, Ks[i], wc[0]))
 
 
+@pytest.mark.parametrize("n", [37, 2048, 8190, 8192, 8193, 9500])
+def test_symcut_selection_paths_bit_exact(gpu, oracle_native, n):
+    """The 50-nearest selection of the part cut keeps a cloud's distance keys in registers up to 8 192 rows and re-reads
+    them from memory beyond that: both paths, ragged sizes around the boundary, and a cloud with many DUPLICATE features
+    (ties at the selection threshold go to the smaller row) against the oracle."""
+    from corsair_amd import backend as B, registration as R
+
+    rng = np.random.default_rng(n)
+    f = rng.standard_normal((n, 16)).astype(np.float32)
+    f[n // 3:n // 3 + min(200, n // 4)] = f[0]              # 200 copies of row 0: a tie block across the threshold
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    x = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    anchors = R.draw_anchors(n, 12, 7)
+    anchors[0] = 0                                           # an anchor inside the tie block
+    c, cnt, mcd, mer = B.symcut_fit(torch.from_numpy(f).to(gpu), torch.from_numpy(x).to(gpu), [0, n],
+                                    torch.from_numpy(anchors[None]).to(gpu), [4], 50, 10, 300)
+    wc, wcnt, wmcd, wmer = oracle_native.symcut_fit(f, x, anchors, 4, 50, 10, 300, 0)
+    assert np.array_equal(cnt[0].cpu().numpy(), wcnt)
+    assert np.array_equal(c[0].cpu().numpy(), wc)
+    assert np.array_equal(mcd[0].cpu().numpy(), wmcd)
+    assert np.array_equal(mer[0].cpu().numpy(), wmer)
+
+
 def test_sym_pose_matches_oracle(gpu, oracle_native):
     """Whole sym_pose (utils/symmetry.py:262-358) on ResUNet features of posed copies of two clouds."""
     from corsair_amd import registration as R
