@@ -1291,12 +1291,22 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
                                                           int32_t* __restrict__ res_cnt,
                                                           unsigned long long* __restrict__ err_by_h,
                                                           const int32_t* __restrict__ hlist,
-                                                          const int32_t* __restrict__ n_surv, int list_stride) {
+                                                          const int32_t* __restrict__ n_surv, int list_stride,
+                                                          // fused k_ransac_stage2_survivors (cnt2 != nullptr): entry c of the
+                                                          // first-stage list is skipped when its second-stage bound is below the best
+                                                          const int32_t* __restrict__ cnt2) {
   const int p = blockIdx.y;
   const RansacProb pr = probs[p];
   if (pr.done) return;
   const int nlist = n_surv[p];
-  if ((int)blockIdx.z >= nlist) return;
+  // entries beyond the capacity of the compact list were not looked at by the second stage: they pass unfiltered
+  auto next_entry = [&](int c) {
+    if (cnt2)
+      while (c < nlist && c < PF_S2_CAP && cnt2[(int64_t)p * PF_S2_CAP + c] < pr.best_cnt) c += gridDim.z;
+    return c;
+  };
+  int c = next_entry(blockIdx.z);
+  if (c >= nlist) return;
   const int tid = threadIdx.x;
   const int per = (pr.m + gridDim.x - 1) / gridDim.x;
   const int i0 = blockIdx.x * per, i1 = min(pr.m, i0 + per);
@@ -1317,17 +1327,18 @@ __global__ __launch_bounds__(256) void k_ransac_count_few(const RansacProb* __re
   }
   // the next survivor's hypothesis is requested before the current one is evaluated: list entry -> twelve strided f64
   // loads are two dependent trips to L2 (~2 us), as long as the 8 x 22 f64 operations per thread they feed
-  int hn = hlist[(int64_t)p * list_stride + blockIdx.z];
+  int hn = hlist[(int64_t)p * list_stride + c];
   double Rn[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
-  for (int c = blockIdx.z; c < nlist; c += gridDim.z) {
+  for (; c < nlist;) {
     const int h = hn;
     double R[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) R[e] = Rn[e];
-    if (c + (int)gridDim.z < nlist) {
-      hn = hlist[(int64_t)p * list_stride + c + gridDim.z];
+    c = next_entry(c + gridDim.z);
+    if (c < nlist) {
+      hn = hlist[(int64_t)p * list_stride + c];
 #pragma unroll
       for (int e = 0; e < 12; ++e) Rn[e] = hyp[((int64_t)p * 12 + e) * bmax + hn];
     }
@@ -1380,12 +1391,21 @@ __global__ __launch_bounds__(256) void k_ransac_scan1(RansacProb* probs, int n_p
                                                      const int32_t* __restrict__ res_cnt, int it0,
                                                      int bcount, int bmax, int ransac_n,
                                                      int max_iter, double log_1mc,
-                                                     int32_t* __restrict__ cand, int* n_active) {
+                                                     int32_t* __restrict__ cand, int* n_active,
+                                                     // fused k_ransac_scan2 (err_by_h != nullptr: k_ransac_count_few left the
+                                                     // error of every survivor, so no k_ransac_err has to run in between)
+                                                     const unsigned long long* __restrict__ err_by_h,
+                                                     const double* __restrict__ hyp, int32_t* __restrict__ next_nsurv,
+                                                     int* __restrict__ next_nactive) {
   // The chunk's counts are staged in LDS by all four waves (coalesced), then wave 0 replays them: lane l
   // owns the contiguous segment [l seg, (l+1) seg).  Element h of lane l sits at h + l, which spreads
   // the lanes' same-offset reads over the banks.
   extern __shared__ int32_t lcnt[];
   const int p = blockIdx.x;
+  if (err_by_h && threadIdx.x == 0) {   // what k_ransac_scan2 clears for the next round (the other parity's counters)
+    next_nsurv[p] = 0;
+    if (p == 0) *next_nactive = 0;
+  }
   RansacProb pr = probs[p];
   if (pr.done) return;
   const int seg = (bcount + 63) / 64;
@@ -1440,19 +1460,44 @@ __global__ __launch_bounds__(256) void k_ransac_scan1(RansacProb* probs, int n_p
   if (cmax > pr.best_cnt) new_ek = est_bound(cmax, pr.m, ransac_n, log_1mc, pr.est_k);
   // 4. candidates: evaluated hypotheses that tie for the best count (ascending order)
   int ncand = 0;
+  // fused scan2: the sequential rule "take candidate c if the count rose or its error is strictly below the best so far" ends
+  // at the FIRST candidate (ascending hypothesis) of the smallest error, provided the count rose or that error is below
+  // the carried one -- a lexicographic (error, hypothesis) minimum over the lanes' segments
+  unsigned long long e_min = ~0ULL;
+  int h_min = 0x7fffffff;
   if (cmax > 0 && cmax >= pr.best_cnt) {
-    int mine = 0;
-    for (int h = s0; h < min(s1, stop); ++h) mine += cnt[h] == cmax;
-    int incl2 = mine;
+    if (err_by_h) {
+      for (int h = s0; h < min(s1, stop); ++h)
+        if (cnt[h] == cmax) {
+          const unsigned long long e = err_by_h[(int64_t)p * bmax + h];
+          if (e < e_min) {   // strict: the earlier hypothesis keeps a tie
+            e_min = e;
+            h_min = h;
+          }
+        }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl2, off);
-      if (lane >= off) incl2 += o;
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long eo = __shfl_xor(e_min, off);
+        const int ho = __shfl_xor(h_min, off);
+        if (eo < e_min || (eo == e_min && ho < h_min)) {
+          e_min = eo;
+          h_min = ho;
+        }
+      }
+    } else {
+      int mine = 0;
+      for (int h = s0; h < min(s1, stop); ++h) mine += cnt[h] == cmax;
+      int incl2 = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl2, off);
+        if (lane >= off) incl2 += o;
+      }
+      int pos = incl2 - mine;
+      ncand = __shfl(incl2, 63);
+      for (int h = s0; h < min(s1, stop); ++h)
+        if (cnt[h] == cmax) cand[(int64_t)p * bmax + pos++] = h;
     }
-    int pos = incl2 - mine;
-    ncand = __shfl(incl2, 63);
-    for (int h = s0; h < min(s1, stop); ++h)
-      if (cnt[h] == cmax) cand[(int64_t)p * bmax + pos++] = h;
   }
   if (lane == 0) {
     const int consumed = it0 + stop;
@@ -1465,7 +1510,13 @@ __global__ __launch_bounds__(256) void k_ransac_scan1(RansacProb* probs, int n_p
     } else {
       atomicAdd(n_active, 1);
     }
-    // best_* are updated by scan2; keep everything else
+    if (err_by_h && h_min != 0x7fffffff && (cmax > pr.best_cnt || e_min < pr.best_err)) {
+      pr.best_cnt = cmax;
+      pr.best_err = e_min;
+      pr.best_itr = it0 + h_min;
+      for (int c = 0; c < 12; ++c) pr.best_T[c] = hyp[((int64_t)p * 12 + c) * bmax + h_min];
+    }
+    // (unfused: best_* are updated by scan2; keep everything else)
     probs[p] = pr;
   }
 }
@@ -2007,6 +2058,7 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           if (getenv("CS_RANSAC_FEW_SLICES")) fslices = std::max(1, atoi(getenv("CS_RANSAC_FEW_SLICES")));
           const int32_t* list_p = hlist.p;
           const int32_t* list_n = d_nsurv;
+          const int32_t* list_cnt2 = nullptr;
           int list_stride = bmax;
           const int s2_pslots = cur.pslots;
           const int32_t* s2_xcd_prob = cur.xcd_prob;
@@ -2022,13 +2074,22 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
             hipLaunchKernelGGL((k_ransac_prefilter<2, false>), dim3((unsigned)(8 * s2_pslots * s2tiles * s2splits)), dim3(256), 0,
                                s, d_probs, off16.p, B32.p, A16s.p, c_hs.p, 0, PF_S2_CAP, PF_S2_CAP, s2splits, s2_xcd_prob,
                                s2_xtab, s2_pslots, s2tiles, cnt2.p, (unsigned long long*)nullptr, d_nsurv);
-            hipLaunchKernelGGL(k_ransac_stage2_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256), 0, s,
-                               d_probs, hlist.p, d_nsurv, bmax, cnt2.p, hlist2.p, n_surv2.p, s2_total.p);
-            list_p = hlist2.p;
-            list_n = n_surv2.p;
+            // the list filter of the second stage runs inside k_ransac_count_few (it skips the entries whose K = 32 bound is
+            // below the best); the separate compaction kernel only for the statistics / CS_RANSAC_FUSE_S2LIST=0
+            static const bool fuse_s2 = !(getenv("CS_RANSAC_FUSE_S2LIST") && getenv("CS_RANSAC_FUSE_S2LIST")[0] == '0') &&
+                                        !getenv("CS_RANSAC_STAGE2_STATS");
+            if (fuse_s2) {
+              list_cnt2 = cnt2.p;
+            } else {
+              hipLaunchKernelGGL(k_ransac_stage2_survivors, dim3((unsigned)((b + 255) / 256), (unsigned)n_prob), dim3(256), 0, s,
+                                 d_probs, hlist.p, d_nsurv, bmax, cnt2.p, hlist2.p, n_surv2.p, s2_total.p);
+              list_p = hlist2.p;
+              list_n = n_surv2.p;
+            }
           }
           hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
-                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, list_p, list_n, list_stride);
+                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, list_p, list_n, list_stride,
+                             list_cnt2);
           err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists
@@ -2053,14 +2114,21 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     static const hipError_t scan1_lds = hipFuncSetAttribute(
         reinterpret_cast<const void*>(k_ransac_scan1), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     CS_REQUIRE(scan1_lds == hipSuccess, CS_ERR_HIP, "cs_ransac_batch: cannot reserve LDS for k_ransac_scan1");
+    // the best-candidate update (k_ransac_scan2) runs inside scan1 when the errors of all survivors are already known
+    // (CS_RANSAC_FUSE_SCAN=0: three kernels as before)
+    static const bool fuse_scan = !(getenv("CS_RANSAC_FUSE_SCAN") && getenv("CS_RANSAC_FUSE_SCAN")[0] == '0');
+    const bool fused_scan = err_known && fuse_scan;
     hipLaunchKernelGGL(k_ransac_scan1, dim3((unsigned)n_prob), dim3(256), sizeof(int32_t) * (b + 64), s, d_probs, n_prob,
-                       res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive);
+                       res_cnt.p, it0, b, bmax, ransac_n, max_iter, log_1mc, cand.p, d_nactive,
+                       fused_scan ? cand_err.p : (const unsigned long long*)nullptr, hyp_r, nsurv_of(cur.par ^ 1),
+                       nactive_of(cur.par ^ 1));
     if (!err_known)
       hipLaunchKernelGGL(k_ransac_err, dim3(8, (unsigned)n_prob), dim3(256), 0, s, d_probs, pk.p,
                          tot1, hyp_r, bmax, cand.p, thr2, scale, cand_err.p);
-    hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
-                       d_probs, n_prob, hyp_r, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax, nsurv_of(cur.par ^ 1),
-                       nactive_of(cur.par ^ 1));
+    if (!fused_scan)
+      hipLaunchKernelGGL(k_ransac_scan2, dim3((unsigned)ceil_div(n_prob, 64)), dim3(64), 0, s,
+                         d_probs, n_prob, hyp_r, cand.p, cand_err.p, err_known ? 1 : 0, it0, bmax, nsurv_of(cur.par ^ 1),
+                         nactive_of(cur.par ^ 1));
     CS_LAUNCH_CHECK();
     // the per-problem state (est_k, done), the survivor counts and the activity counter come back in
     // one copy behind a synchronisation the chunk loop needs anyway
