@@ -10,7 +10,8 @@
 //                       rigid fit (Horn quaternion; largest eigenpair of the 4x4 matrix from its characteristic
 //                       polynomial, horn_qcp, with the Jacobi eigen-solver as per-lane fallback; f64), emit R|t as f64
 //                       (Open3D keeps the Matrix4d; the f32 cast happens at the very end, where the
-//                       reference casts the result: utils/symmetry.py:274)
+//                       reference casts the result: utils/symmetry.py:274); from iteration 256 on it also emits the
+//                       hypothesis' prefilter row (pf_emit_row: 16 f16 coefficients + c_h)
 //   k_ransac_prefilter  (from iteration 256 on) an UPPER bound of every hypothesis' inlier count on the
 //                       f16 matrix cores; hypotheses whose bound is below the carried best cannot
 //                       matter and get count 0.  Round 4: <1, true> = one MFMA per tile (K = 16: a_hi . b_hi',
@@ -35,6 +36,8 @@
 //                       when k_ransac_count_few has not produced it already)
 //   k_ransac_scan2      best = max count, then min error, then first -- the final state of the
 //                       sequential rule "better = more inliers, or equal inliers and smaller rmse"
+//                       (inside k_ransac_scan1 whenever k_ransac_count_few has left the errors: the usual round is
+//                       hyp -> prefilter -> survivors -> second-stage prefilter -> count_few -> scan1, six launches)
 // The host loop synchronises once per chunk (one pinned copy of the per-problem state); the next
 // chunk's hypotheses are already enqueued at that point.
 // Inlier counts and fixed-point errors are integers, so any split of the correspondence range across
