@@ -93,6 +93,10 @@ def parse():
                     help="chair, 1 GPU: skip the short table (configs[2]) and stress (configs[4]) legs reported as `workloads`")
     ap.add_argument("--sequential-value", action="store_true",
                     help="report the one-batch-at-a-time pass as `value` even when the three-batches-in-flight pass ran")
+    ap.add_argument("--embed-group", type=int, default=4,
+                    help="N consecutive steps of the chair / table workload share one forward of the network in the "
+                         "one-batch-at-a-time pass (N x 32 clouds; retrieval and registration stay per step of 32 queries); "
+                         "1: one forward per step")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra pass with three batches in flight reported as `batches_in_flight`")
     return ap.parse_args()
@@ -364,10 +368,29 @@ class RegistrationWorkload:
                 % (self.kind, C, self.catalog_embed_s, n_b))
 
     def step(self, b):
+        self._retrieve_and_register(b, self.pipe.embed_batch(self.q_dev[b], self.q_off[b]))
+
+    def step_group(self, steps):
+        """Consecutive steps whose query batches go through ONE forward of the network (a 32-cloud batch
+        leaves the stride-4 / 8 layers with fewer workgroups than the chip has CUs).  Each step still retrieves and
+        registers its own 32 queries.  Batch composition changes no row -- eval-mode BatchNorm, a convolution row is the
+        same fma chain whatever else is in the batch, pooling is per sample -- so the results are those of step() calls
+        bit for bit (checked in every run against the pass with one forward per step: `batches_in_flight.identical_results`)."""
+        from corsair_amd import harness
+
+        both = self.pipe.embed_groups([(self.q_dev[b], self.q_off[b]) for b in steps])
+        off = both.offsets
+        for j, b in enumerate(steps):
+            lo = j * BATCH
+            r0, r1 = off[lo], off[lo + BATCH]
+            qs = harness.EmbeddedSet(both.F[r0:r1], both.origin[r0:r1], [o - r0 for o in off[lo:lo + BATCH + 1]],
+                                     both.desc[lo:lo + BATCH])
+            self._retrieve_and_register(b, qs)
+
+    def _retrieve_and_register(self, b, qs):
         from corsair_amd import _lib, registration
 
         pipe, catalog, rank, n_q = self.pipe, self.catalog, self.ctx.rank, self.n_q
-        qs = pipe.embed_batch(self.q_dev[b], self.q_off[b])
         ids = [(2 * (rank * n_q + b * BATCH + i), 2 * (rank * n_q + b * BATCH + i) + 1) for i in range(BATCH)]
         # host work that only needs the voxel counts goes here, while the convolutions are still running
         q_anc = [registration.draw_anchors(qs.offsets[i + 1] - qs.offsets[i], 100, ids[i][0]) for i in range(BATCH)]
@@ -826,6 +849,7 @@ class Runner:
         import torch
 
         self.ctx, self.wl, self.depth = ctx, wl, depth
+        self.group = max(1, int(getattr(ctx.args, "embed_group", 1)))
         self.streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 3))]
         self.workers = {}
 
@@ -841,16 +865,29 @@ class Runner:
 
         depth = self.depth if depth is None else depth
         wl, ctx, streams = self.wl, self.ctx, self.streams
+        # work items of this range: single steps, or -- a workload with step_group and --embed-group N > 1 -- groups of N
+        # consecutive steps that share one forward of the network (formed from `first`: never across the timed region's edge).
+        # (only one batch at a time: with several in flight a group is a coarser work item, which costs more at the ragged end
+        # of a short run than the shared forward saves -- that pass keeps one forward per step)
+        n_grp = self.group if (depth == 1 and hasattr(wl, "step_group")) else 1
+        items = [tuple(range(b, min(b + n_grp, last))) for b in range(first, last, n_grp)]
+
+        def run(item):
+            if len(item) > 1:
+                wl.step_group(list(item))
+            else:
+                wl.step(item[0])
+
         if depth == 1:
-            for b in range(first, last):
-                wl.step(b)
+            for item in items:
+                run(item)
             return
 
         def work(w):
             torch.cuda.set_device(ctx.dev_index)
             with torch.cuda.stream(streams[w]):
-                for b in range(first + w, last, depth):
-                    wl.step(b)
+                for item in items[w::depth]:
+                    run(item)
                 streams[w].synchronize()
 
         futures = [self.worker_of(w).submit(work, w) for w in range(depth)]
@@ -1051,6 +1088,8 @@ def main():
         piped = overlap is not None and overlap[1] and not args.sequential_value and overlap[0] < elapsed
         head_elapsed = overlap[0] if piped else elapsed
         cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": 3 if piped else depth})
+        if hasattr(wl, "step_group"):
+            cfg["embed_batches_per_forward"] = max(1, args.embed_group)   # sequential pass; the pass with batches in flight: 1
         out = {
             "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD %s"
                       % ("chair" if args.workload == "stress" else args.workload),

@@ -31,6 +31,10 @@ class Config:
     random_seed: int = 31
     n_points: int = 10000
     batch_size: int = 32
+    # clouds per forward of the network when the caller gives no batch size of its own.  The reference's DataLoader hands the
+    # network 32 (= batch_size); the rows of an eval-mode forward do not depend on what else is in the batch, and a 32-cloud
+    # batch leaves the stride-4 / 8 layers with fewer workgroups than the chip has CUs: 128 here
+    embed_batch_size: int = 128
     ransac_max_iter: int = 100000
     ransac_confidence: float = 0.999
 
@@ -114,8 +118,8 @@ class Pipeline:
     def embed_clouds(self, clouds, batch_size=None):
         """clouds: list of f32 or f64 [n,3] NumPy arrays (host), one type per call: a cloud is quantised in
         the type it arrives in, so promoting or narrowing here would move points across voxel boundaries.
-        Batches of batch_size like the reference's DataLoader(bs=32)."""
-        bs = batch_size or self.cfg.batch_size
+        Forwards of batch_size clouds (default cfg.embed_batch_size; the reference's DataLoader: 32 -- same rows either way)."""
+        bs = batch_size or self.cfg.embed_batch_size
         kinds = {np.asarray(c).dtype for c in clouds}
         if len(kinds) > 1 or not kinds <= {np.dtype(np.float32), np.dtype(np.float64)}:
             raise TypeError("embed_clouds: clouds must all be float32 or all be float64, got %s" % sorted(map(str, kinds)))
@@ -243,8 +247,9 @@ def run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, cat
 
     cfg = pipe.cfg
     bs = batch_size or cfg.batch_size
-    cat = catalog if isinstance(catalog, EmbeddedSet) else pipe.embed_clouds(catalog, bs)
-    qs = queries if isinstance(queries, EmbeddedSet) else pipe.embed_clouds(queries, bs)
+    ebs = cfg.embed_batch_size   # (batch_size is the REGISTRATION batch; the network's forward has its own size)
+    cat = catalog if isinstance(catalog, EmbeddedSet) else pipe.embed_clouds(catalog, ebs)
+    qs = queries if isinstance(queries, EmbeddedSet) else pipe.embed_clouds(queries, ebs)
     Q = len(qs)
     best_match = np.asarray(best_match).astype(np.int64)
     syms = np.asarray(syms)
@@ -449,7 +454,9 @@ def build_parser():
     ap.add_argument("--register-gt", action="store_false", dest="register_top1", help="register the annotated CAD")
     ap.add_argument("--ignore-cache", action="store_true")
     ap.add_argument("--n-points", type=int, default=10000)
-    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--batch-size", type=int, default=32, help="queries per registration batch")
+    ap.add_argument("--embed-batch-size", type=int, default=128,
+                    help="clouds per forward of the network (the reference's DataLoader: 32; the rows do not depend on it)")
     ap.add_argument("--ransac-max-iter", type=int, default=100000)
     ap.add_argument("--in-flight", type=int, default=3, help="registration batches in flight (host threads x HIP streams)")
     ap.add_argument("--device", default="cuda", choices=["cuda"], help="there is no CPU path")
@@ -465,7 +472,8 @@ def main(argv=None):
     sd, esd = ckpts.load_state_dicts(a.checkpoint)
     if esd is None:
         raise SystemExit("checkpoint has no embedding_state_dict: retrieval needs the descriptor head (evaluation.py:199)")
-    cfg = Config(n_points=a.n_points, batch_size=a.batch_size, ransac_max_iter=a.ransac_max_iter)
+    cfg = Config(n_points=a.n_points, batch_size=a.batch_size, embed_batch_size=a.embed_batch_size,
+                 ransac_max_iter=a.ransac_max_iter)
     pipe = Pipeline(sd, esd, device=a.device, config=cfg)
     cad_names, catalog = load_cloud_dir(a.catalog_dir, a.n_points, "catalog")
     _, queries = load_cloud_dir(a.query_dir, a.n_points, "queries")

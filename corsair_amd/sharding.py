@@ -226,11 +226,12 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
     best_match = np.asarray(best_match).astype(np.int64)
     syms = np.asarray(syms)
     # 1. catalog (an EmbeddedSet = already embedded and gathered, e.g. once for several evaluations)
-    cat = catalog if isinstance(catalog, EmbeddedSet) else embed_catalog_sharded(pipe, dist, rank, world, catalog, bs)
+    ebs = cfg.embed_batch_size   # (batch_size is the registration batch)
+    cat = catalog if isinstance(catalog, EmbeddedSet) else embed_catalog_sharded(pipe, dist, rank, world, catalog, ebs)
     # 2. queries
     qshards = voxel_balanced_shards(dist, pipe, queries, rank, world)
     mine = np.asarray(qshards[rank], dtype=np.int64)
-    qs = pipe.embed_clouds([queries[q] for q in mine], bs) if len(mine) else _empty_set(dev)
+    qs = pipe.embed_clouds([queries[q] for q in mine], ebs) if len(mine) else _empty_set(dev)
     q_max = max(len(s_) for s_ in qshards)
     order = shard_order(qshards)
     descs = _all_gather_padded(dist, qs.desc, q_max, world)
