@@ -986,6 +986,8 @@ def extra_workload_leg(ctx, args, name):
            "config": cfg, "roofline": roofline_of(fam, None, leg_args),
            "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()}}
     leg["roofline"]["pass"] = "sequential"
+    if hasattr(wl, "step_group"):
+        leg["config"]["embed_batches_per_forward"] = max(1, leg_args.embed_group)   # sequential pass (see the headline's note)
     if name == "stress":
         leg["kernel_tflops"] = {k: round(fam[k]["flop"] / max(fam[k]["ms"], 1e-9) / 1e9, 2) for k in ("conv", "topk")}
         leg["est_full_job_s"] = 100000.0 / leg["value"]   # 100 k clouds + the whole 10^6 x 10^6 top-10
@@ -1123,7 +1125,10 @@ def main():
         wl.extras(out)
         out["sequential"] = {"value": total_units / elapsed, "unit": "queries/s", "ms_per_step": elapsed / args.steps * 1e3,
                              "note": "the same K steps one batch at a time (the pass `roofline`, `roofline_by_kernel` and "
-                                     "`kernel_ms` are measured over: their launches share the GPU only with their own step)"}
+                                     "`kernel_ms` are measured over: their launches share the GPU only with their own step)"
+                                     + ("; %d consecutive steps' query batches share one forward of the network, retrieval and "
+                                        "registration per step" % args.embed_group
+                                        if hasattr(wl, "step_group") and args.embed_group > 1 and depth == 1 else "")}
         out["roofline"]["pass"] = "sequential"
         if overlap:
             out["batches_in_flight"] = {
