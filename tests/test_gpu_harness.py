@@ -99,3 +99,32 @@ def test_run_eval_with_batches_in_flight_equals_the_sequential_loop(gpu, small_e
     assert seq.stat == par.stat and seq.report == par.report
     for k in cache.NAMES:
         assert seq.per_query[k].dtype == par.per_query[k].dtype and np.array_equal(seq.per_query[k], par.per_query[k]), k
+
+
+def test_bench_grouped_forward_equals_one_forward_per_step(gpu, monkeypatch):
+    """bench.py's sequential pass sends several steps' query batches through ONE forward of the network
+    (RegistrationWorkload.step_group, --embed-group): retrieval ids, transforms, Chamfer distances and iteration counts of
+    every step equal those of one forward per step bit for bit (batch composition changes no row)."""
+    import sys
+
+    import bench
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--catalog", "24", "--steps", "3", "--warmup", "0"])
+    args = bench.parse()
+    ctx = bench.Ctx(args)
+    wl = bench.RegistrationWorkload(ctx, "chair")
+    wl.setup()
+    for b in range(3):
+        wl.step(b)
+    single = {r[0]: r for r in wl.results}
+    wl.results.clear()
+    wl.step_group([0, 1, 2])
+    assert sorted(r[0] for r in wl.results) == [0, 1, 2]
+    for r in wl.results:
+        s = single[r[0]]
+        assert np.array_equal(r[1], s[1])                       # retrieved CAD ids
+        for i in (2, 3, 4, 6):                                  # T_best, T_ransac, Chamfer, iterations
+            assert np.array_equal(r[i], s[i]), i
+        assert wl.same_results(r, s)
