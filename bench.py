@@ -94,9 +94,8 @@ def parse():
     ap.add_argument("--sequential-value", action="store_true",
                     help="report the one-batch-at-a-time pass as `value` even when the three-batches-in-flight pass ran")
     ap.add_argument("--embed-group", type=int, default=4,
-                    help="N consecutive steps of the chair / table workload share one forward of the network in the "
-                         "one-batch-at-a-time pass (N x 32 clouds; retrieval and registration stay per step of 32 queries); "
-                         "1: one forward per step")
+                    help="N consecutive steps of the chair / table workload share one forward of the network "
+                         "(N x 32 clouds; retrieval and registration stay per step of 32 queries); 1: one forward per step")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra pass with three batches in flight reported as `batches_in_flight`")
     return ap.parse_args()
@@ -375,17 +374,26 @@ class RegistrationWorkload:
         leaves the stride-4 / 8 layers with fewer workgroups than the chip has CUs).  Each step still retrieves and
         registers its own 32 queries.  Batch composition changes no row -- eval-mode BatchNorm, a convolution row is the
         same fma chain whatever else is in the batch, pooling is per sample -- so the results are those of step() calls
-        bit for bit (checked in every run against the pass with one forward per step: `batches_in_flight.identical_results`)."""
+        bit for bit (tests/test_gpu_harness.py::test_bench_grouped_forward_equals_one_forward_per_step)."""
+        for b, qs in self.embed_steps(steps).items():
+            self._retrieve_and_register(b, qs)
+
+    def embed_steps(self, steps):
+        """One forward for the query batches of `steps`; {step: EmbeddedSet (row slices of the shared tensors)}."""
         from corsair_amd import harness
 
         both = self.pipe.embed_groups([(self.q_dev[b], self.q_off[b]) for b in steps])
         off = both.offsets
+        out = {}
         for j, b in enumerate(steps):
             lo = j * BATCH
             r0, r1 = off[lo], off[lo + BATCH]
-            qs = harness.EmbeddedSet(both.F[r0:r1], both.origin[r0:r1], [o - r0 for o in off[lo:lo + BATCH + 1]],
-                                     both.desc[lo:lo + BATCH])
-            self._retrieve_and_register(b, qs)
+            out[b] = harness.EmbeddedSet(both.F[r0:r1], both.origin[r0:r1], [o - r0 for o in off[lo:lo + BATCH + 1]],
+                                         both.desc[lo:lo + BATCH])
+        return out
+
+    def register_step(self, b, qs):
+        self._retrieve_and_register(b, qs)
 
     def _retrieve_and_register(self, b, qs):
         from corsair_amd import _lib, registration
@@ -451,6 +459,11 @@ class RegistrationWorkload:
         ps = (ctypes.c_uint64 * 3)()
         _lib.load().cs_pool_stats(ps)
         out["scratch_pool"] = {"live_blocks": int(ps[0]), "freed_by_a_foreign_thread": int(ps[1])}
+        import torch
+
+        ms = torch.cuda.memory_stats()
+        out["torch_allocator"] = {"device_mallocs": int(ms.get("num_device_alloc", 0)), "device_frees": int(ms.get("num_device_free", 0)),
+                                  "reserved_gb": round(torch.cuda.memory_reserved() / 1e9, 3)}
 
     def cpu_baseline(self):
         """The CPU oracle (kind "port": the build's restatement of the reference CPU path, OpenMP over
@@ -865,29 +878,61 @@ class Runner:
 
         depth = self.depth if depth is None else depth
         wl, ctx, streams = self.wl, self.ctx, self.streams
-        # work items of this range: single steps, or -- a workload with step_group and --embed-group N > 1 -- groups of N
-        # consecutive steps that share one forward of the network (formed from `first`: never across the timed region's edge).
-        # (only one batch at a time: with several in flight a group is a coarser work item, which costs more at the ragged end
-        # of a short run than the shared forward saves -- that pass keeps one forward per step)
-        n_grp = self.group if (depth == 1 and hasattr(wl, "step_group")) else 1
-        items = [tuple(range(b, min(b + n_grp, last))) for b in range(first, last, n_grp)]
-
-        def run(item):
-            if len(item) > 1:
-                wl.step_group(list(item))
-            else:
-                wl.step(item[0])
-
+        # A workload with step_group and --embed-group N > 1: the query batches of N consecutive steps go through ONE forward
+        # of the network (groups formed from `first`: never across the timed region's edge); retrieval and registration stay
+        # per step.  One batch at a time: a group is the work item.  Several in flight: the STEP stays the work item (a group
+        # would be too coarse at the ragged end of a short run); the worker that first needs a group runs its forward on its own
+        # stream, the others wait for that stream's event and then register their steps -- one forward per group, three
+        # registrations in flight.
+        n_grp = self.group if hasattr(wl, "step_group") else 1
         if depth == 1:
-            for item in items:
-                run(item)
+            for b in range(first, last, n_grp):
+                item = list(range(b, min(b + n_grp, last)))
+                if len(item) > 1:
+                    wl.step_group(item)
+                else:
+                    wl.step(item[0])
             return
+
+        import threading
+        from concurrent.futures import Future
+
+        lock = threading.Lock()
+        shared = {}      # group index -> Future of ({step: EmbeddedSet}, event recorded behind the forward)
+
+        def embedded(b):
+            g = (b - first) // n_grp
+            with lock:
+                fut = shared.get(g)
+                mine = fut is None
+                if mine:
+                    fut = shared[g] = Future()
+            if mine:
+                try:
+                    steps = list(range(first + g * n_grp, min(first + (g + 1) * n_grp, last)))
+                    sets = wl.embed_steps(steps)
+                    ev = torch.cuda.Event()
+                    ev.record()                       # on this worker's stream, behind the forward
+                    fut.set_result((sets, ev))
+                except BaseException as e:            # noqa: BLE001 -- the waiting workers must not hang
+                    fut.set_exception(e)
+                    raise
+            sets, ev = fut.result()
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            qs = sets[b]
+            for t in (qs.F, qs.origin, qs.desc):     # allocated on the embedding worker's stream, used on this one
+                t.record_stream(cur)
+            return qs
 
         def work(w):
             torch.cuda.set_device(ctx.dev_index)
             with torch.cuda.stream(streams[w]):
-                for item in items[w::depth]:
-                    run(item)
+                for b in range(first + w, last, depth):
+                    if n_grp > 1:
+                        wl.register_step(b, embedded(b))
+                    else:
+                        wl.step(b)
                 streams[w].synchronize()
 
         futures = [self.worker_of(w).submit(work, w) for w in range(depth)]
@@ -913,6 +958,13 @@ def timed_region(ctx, wl, runner, warmup, steps):
     wl.results.clear()
     _lib.prof_enable(True)
     _lib.prof_reset()
+    # Everything allocated so far (the catalog, K + W batches of query clouds, the network) is long-lived: moved to the
+    # permanent generation so that a full collection of Python's cycle collector inside the timed region does not walk it
+    # (measured: 10 - 50 ms pauses in some steps of a 20-step run, 1 360 vs 1 485 q/s; BENCH_GC=1 keeps the default)
+    import gc
+    if os.environ.get("BENCH_GC", "freeze") == "freeze":
+        gc.collect()
+        gc.freeze()
     ctx.barrier()
     t_start = time.time()
     runner.run_steps(warmup, warmup + steps)
@@ -1091,7 +1143,7 @@ def main():
         head_elapsed = overlap[0] if piped else elapsed
         cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": 3 if piped else depth})
         if hasattr(wl, "step_group"):
-            cfg["embed_batches_per_forward"] = max(1, args.embed_group)   # sequential pass; the pass with batches in flight: 1
+            cfg["embed_batches_per_forward"] = max(1, args.embed_group)   # both passes
         out = {
             "metric": "end-to-end queries/sec (embed+retrieve+register), Scan2CAD %s"
                       % ("chair" if args.workload == "stress" else args.workload),

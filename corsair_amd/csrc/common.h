@@ -168,6 +168,10 @@ struct cs_kernelmap {
   hipEvent_t cnt_ready = nullptr;
   unsigned long long* h_cnt = nullptr;
   int cnt_slot = -1;
+  // profiling only: FLOP per pair of the convolutions that ran on this map while its pair count was still on the way
+  // (2 Cin Cout each); turned into work units when the count is known (kernelmap_pairs / cs_kernelmap_free) instead of
+  // stalling the host in cs_conv_fwd
+  double prof_flop_per_pair = 0.0;
 };
 namespace cs {
 int64_t kernelmap_pairs(const cs_kernelmap* km);

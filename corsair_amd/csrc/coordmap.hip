@@ -489,6 +489,10 @@ int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
     if (hipEventSynchronize(km->cnt_ready) != hipSuccess) return -1;
     km->num_pairs = (int64_t)*km->h_cnt;
   }
+  if (km->num_pairs >= 0 && km->prof_flop_per_pair > 0.0) {   // convolutions profiled before the count had arrived
+    prof_add_units("conv", km->prof_flop_per_pair * (double)km->num_pairs);
+    km->prof_flop_per_pair = 0.0;
+  }
   return km->num_pairs;
 }
 
@@ -1271,6 +1275,7 @@ void cs_kernelmap_free(cs_kernelmap* km) {
   pool_free(km->d_gmask);
   if (km->cnt_ready) {
     (void)hipEventSynchronize(km->cnt_ready);  // the slot must not be recycled under a pending copy
+    if (km->prof_flop_per_pair > 0.0) (void)cs::kernelmap_pairs(km);   // hands the deferred work units to the profile
     (void)hipEventDestroy(km->cnt_ready);
   }
   count_slot_release(km->cnt_slot);

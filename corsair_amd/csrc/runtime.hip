@@ -89,7 +89,8 @@ void* pool_alloc(size_t bytes) {
   if (it != t_cache.free_.end() && !it->second.empty()) {
     p = it->second.back();
     it->second.pop_back();
-  } else {
+  }
+  if (!p) {
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {
       trim_thread_cache();
@@ -216,6 +217,7 @@ struct ProfPending {
   hipEvent_t e0, e1;
 };
 static std::vector<ProfPending> g_pending[kNumProf];
+static std::vector<hipEvent_t> g_event_pool;   // timing events of finished scopes, reused (under g_prof_mu)
 static double g_prof_ms[kNumProf] = {0};
 static int64_t g_prof_n[kNumProf] = {0};
 static double g_prof_units[kNumProf] = {0};
@@ -234,7 +236,17 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double units) : id(-1), st
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_units[id] += units;
   }
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+  // events come from a free list (refilled by prof_drain): two hipEventCreate per scope were ~1 ms of host time per chair step
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_event_pool.size() >= 2) {
+      e0 = g_event_pool.back();
+      g_event_pool.pop_back();
+      e1 = g_event_pool.back();
+      g_event_pool.pop_back();
+    }
+  }
+  if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
     id = -1;
     return;
   }
@@ -291,8 +303,14 @@ static void prof_drain(int id) {
         g_prof_n[id] += 1;
       }
     }
-    (void)hipEventDestroy(p.e0);
-    (void)hipEventDestroy(p.e1);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_event_pool.size() < 16384) {
+      g_event_pool.push_back(p.e0);
+      g_event_pool.push_back(p.e1);
+    } else {
+      (void)hipEventDestroy(p.e0);
+      (void)hipEventDestroy(p.e1);
+    }
   }
 }
 
@@ -318,7 +336,18 @@ void cs_pool_stats(uint64_t out[3]) {
   for (int i = 0; i < 3; ++i) out[i] = v[i];
 }
 
-void cs_prof_enable(int on) { cs::g_prof_on = on; }
+void cs_prof_enable(int on) {
+  if (on) {
+    // the events of the region ahead are created here, outside of what is being measured (a scope takes two from the pool)
+    std::lock_guard<std::mutex> lk(cs::g_prof_mu);
+    while (cs::g_event_pool.size() < 8192) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      cs::g_event_pool.push_back(e);
+    }
+  }
+  cs::g_prof_on = on;
+}
 
 void cs_prof_reset(void) {
   for (int i = 0; i < cs::kNumProf; ++i) {
