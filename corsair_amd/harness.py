@@ -496,6 +496,11 @@ def main(argv=None):
     if table.shape != (C, C) or len(best_match) != Q or len(lib_T) != C:
         raise SystemExit(f"shape mismatch: table {table.shape}, best_match {len(best_match)}, lib poses {len(lib_T)} "
                          f"for C = {C}, Q = {Q}")
+    # the clouds and tables loaded above live as long as the process: out of the cycle collector's way (a full collection
+    # otherwise walks them between registration batches: 10 - 50 ms pauses)
+    import gc
+    gc.collect()
+    gc.freeze()
     res = run_eval(pipe, catalog, queries, best_match, table, base_T, lib_T, syms, a.category, a.register_top1,
                    a.cache_dir, a.ignore_cache, False, a.batch_size, a.in_flight)
     print(f"category: {a.category}")
