@@ -1052,6 +1052,12 @@ def extra_workload_leg(ctx, args, name):
 def main():
     args = parse()
     maybe_self_launch(args)
+    # The contract: rank 0 prints ONE JSON line on stdout.  Libraries write there too (torch's gloo backend announces
+    # "[Gloo] Rank 0 is connected to ..." on stdout when the control-plane group comes up): from here on file descriptor 1
+    # is stderr, and the result line goes out through a saved copy of the real stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     from corsair_amd import _lib
@@ -1196,7 +1202,8 @@ def main():
             out["workloads"] = {name: extra_workload_leg(ctx, args, name) for name in ("table", "stress")}
         if ctx.world == 1 and not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
             out["cpu_baseline"] = wl.cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
