@@ -326,15 +326,19 @@ __global__ __launch_bounds__(256) void k_symcut_select(
 // (tests/test_pins_cpu.py).  k_symcut_finish keeps the first restart, then any with smaller inertia AND a
 // different clustering (sklearn's _is_same_clustering).
 __global__ __launch_bounds__(256) void k_symcut_kmeans(const int32_t* __restrict__ Ks, int n_anchor,
-                                                       int n_blk, int n_init, int max_iter,
+                                                       int n_blk, int n_init, int max_iter, int per,
                                                        const double* __restrict__ pts_g,
                                                        const int32_t* __restrict__ nsel_g,
                                                        double* __restrict__ km_centers_g,
                                                        double* __restrict__ km_inertia_g,
                                                        unsigned long long* __restrict__ km_labels_g) {
-  __shared__ double pts_s[8][SYM_MAX_NN][3];  // the points of the (up to 8) cloud-anchors of this workgroup
-  extern __shared__ double closest_s[];       // [n_nn_max][256]: squared distance to the nearest chosen centre
-  const int per = 256 / n_init < 8 ? 256 / n_init : 8;  // cloud-anchors per workgroup
+  // dynamic LDS: [per][SYM_MAX_NN][3] points of this workgroup's cloud-anchors, then [n_nn][256] squared distances to the
+  // nearest chosen centre.  per = cloud-anchors per workgroup, chosen by the host: as many as the 256 lanes have restarts
+  // for and the LDS holds (25 at n_init = 10, n_nn = 50: 250 lanes busy, the 6 400 cloud-anchors of a chair step are ONE
+  // round of 256 workgroups; round 3 capped this at 8 = 80 lanes, three rounds)
+  extern __shared__ double km_lds[];
+  double (*pts_s)[SYM_MAX_NN][3] = reinterpret_cast<double (*)[SYM_MAX_NN][3]>(km_lds);
+  double* closest_s = km_lds + (size_t)per * SYM_MAX_NN * 3;
   const int tid = threadIdx.x;
   const int sub = tid / n_init;                          // which of them this thread works on
   const int blk = blockIdx.x * per + sub;
@@ -758,13 +762,17 @@ int cs_symcut_fit(const float* d_feat, int dim, const float* d_xyz, const int64_
       hipLaunchKernelGGL((k_symcut_select<32>), grid, dim3(256), 0, s, d_feat, d_xyz, d_off.p,
                          d_anchor, n_anchor, d_K.p, n_nn, n_init, max_iter, seed, keys.p,
                          d_koff.p, d_centers, d_counts, d_min_center_dist, d_max_error, pts_g.p, nsel_g.p);
-    const int per = 256 / n_init < 8 ? 256 / n_init : 8;
-    // 100 KB of dynamic LDS for n_nn = 50 (one f64 per thread and selected voxel), above the 64 KB default
-    CS_HIP_CHECK(hipFuncSetAttribute((const void*)k_symcut_kmeans, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(sizeof(double) * 256 * SYM_MAX_NN)));
-    hipLaunchKernelGGL(k_symcut_kmeans, dim3((unsigned)((n_blk + per - 1) / per)), dim3(256),
-                       sizeof(double) * 256 * (size_t)n_nn, s, d_K.p, n_anchor, n_blk, n_init, max_iter,
-                       pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, kml_g.p);
+    // dynamic LDS: 100 KB for n_nn = 50 (one f64 per thread and selected voxel) + 1.5 KB per cloud-anchor of the workgroup
+    const size_t closest_bytes = sizeof(double) * 256 * (size_t)n_nn;
+    const size_t lds_budget = 156 * 1024;
+    int per = 256 / n_init;
+    const int per_fit = (int)((lds_budget - closest_bytes) / (sizeof(double) * SYM_MAX_NN * 3));
+    if (per > per_fit) per = per_fit;
+    if (per < 1) per = 1;
+    const size_t km_lds_bytes = closest_bytes + sizeof(double) * SYM_MAX_NN * 3 * (size_t)per;
+    CS_HIP_CHECK(hipFuncSetAttribute((const void*)k_symcut_kmeans, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
+    hipLaunchKernelGGL(k_symcut_kmeans, dim3((unsigned)((n_blk + per - 1) / per)), dim3(256), km_lds_bytes, s, d_K.p, n_anchor,
+                       n_blk, n_init, max_iter, per, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, kml_g.p);
     hipLaunchKernelGGL((k_symcut_finish<16>), grid, dim3(256), 0, s, d_xyz, d_off.p, n_anchor, d_K.p,
                        n_init, pts_g.p, nsel_g.p, kmc_g.p, kmi_g.p, kml_g.p, d_centers, d_counts,
                        d_min_center_dist, d_max_error);
