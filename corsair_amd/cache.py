@@ -7,6 +7,12 @@ import numpy as np
 
 NAMES = ("Ts_est_ransac", "Ts_est_best", "t_losses_ransac", "t_losses_sym", "r_losses_ransac",
          "r_losses_sym", "sym_ransac_success", "chamfer_dist_ransac", "chamfer_dist_sym")
+# element types of the nine arrays as the registration loop produces them (eval_pose's t_loss is the norm of an f32
+# vector, hence f32; its r_loss goes through np.float64): what an EMPTY result set carries, and what the sharded
+# evaluation puts on the wire -- fixed by NAME so that ranks with and without queries agree on every collective
+DTYPES = {"Ts_est_ransac": np.float32, "Ts_est_best": np.float32, "t_losses_ransac": np.float32,
+          "t_losses_sym": np.float32, "r_losses_ransac": np.float64, "r_losses_sym": np.float64,
+          "sym_ransac_success": np.bool_, "chamfer_dist_ransac": np.float64, "chamfer_dist_sym": np.float64}
 
 
 def _suffix(register_top1):

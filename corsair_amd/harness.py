@@ -290,8 +290,7 @@ def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, for
     bs = batch_size or pipe.cfg.batch_size
     query_ids = np.asarray(query_ids, dtype=np.int64)
     if not len(query_ids):
-        return {k: np.zeros((0, 4, 4), np.float32) if k.startswith("Ts_est") else
-                np.zeros(0, bool if k == "sym_ransac_success" else np.float64) for k in C_.NAMES}
+        return {k: np.zeros((0, 4, 4) if k.startswith("Ts_est") else 0, C_.DTYPES[k]) for k in C_.NAMES}
     batches = [np.arange(s, min(len(query_ids), s + bs)) for s in range(0, len(query_ids), bs)]
 
     def one(loc):

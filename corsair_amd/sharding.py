@@ -155,20 +155,38 @@ def _all_gather_rows(dist, t, world):
 def sharded_topk(dist, q_local, local_topk, shard_first, k, rank, world):
     """Top-k of this rank's queries against a catalog sharded over the ranks (rank r holds the contiguous rows
     [shard_first, shard_first + n_r)).  The QUERIES travel, not the catalog: (1) all-gather the
-    queries (every rank contributes the same number), (2) `local_topk(q_all) -> (local row idx int64 [., k],
-    squared distance f64 [., k])` against the own shard (cs_l2_topk_sq), (3) all-gather the candidate
+    queries (ranks may contribute DIFFERENT numbers, also none: the counts are exchanged first and the payload is
+    padded to the largest), (2) `local_topk(q_all) -> (local row idx int64 [., k], squared distance f64 [., k])`
+    against the own shard (cs_l2_topk_sq) for the real rows of every rank, (3) all-gather the candidate
     (distance, global id) lists, (4) merge the `world` lists of the own queries.  Returns (ids int64 [Q, k],
-    d2 f64 [Q, k]): identical to a single-device top-k over the whole catalog, bit for bit."""
+    d2 f64 [Q, k]): identical to a single-device top-k over the whole catalog, bit for bit.  A rank whose shard is
+    empty (more ranks than catalog rows) contributes lists of (-1, inf)."""
     if dist is None or world == 1:
         idx, d2 = local_topk(q_local)
         return idx + (idx >= 0) * shard_first, d2
-    Q = q_local.shape[0]
-    q_all = _all_gather_rows(dist, q_local, world).reshape(world * Q, -1)
+    Q = int(q_local.shape[0])
+    counts = _all_gather_rows(dist, torch.tensor([Q], dtype=torch.int64, device=q_local.device), world)[:, 0].tolist()
+    q_max = max(counts)
+    if q_max == 0:
+        return (torch.zeros((0, k), dtype=torch.int64, device=q_local.device),
+                torch.zeros((0, k), dtype=torch.float64, device=q_local.device))
+    if min(counts) == q_max:
+        q_all = _all_gather_rows(dist, q_local, world).reshape(world * Q, -1)
+    else:
+        pad = torch.zeros((q_max,) + tuple(q_local.shape[1:]), dtype=q_local.dtype, device=q_local.device)
+        pad[:Q] = q_local
+        got = _all_gather_rows(dist, pad, world)
+        q_all = torch.cat([got[r, : counts[r]] for r in range(world)])
     idx, d2 = local_topk(q_all)
+    if idx.shape[1] < k:         # a shard with fewer than k rows (or none): absent entries are (-1, inf)
+        fill = k - idx.shape[1]
+        idx = torch.cat([idx, torch.full((idx.shape[0], fill), -1, dtype=idx.dtype, device=idx.device)], dim=1)
+        d2 = torch.cat([d2, torch.full((d2.shape[0], fill), float("inf"), dtype=d2.dtype, device=d2.device)], dim=1)
     gid = torch.where(idx >= 0, idx + shard_first, idx)
-    gids = _all_gather_rows(dist, gid, world)                 # [world (shard), world * Q, k]
+    gids = _all_gather_rows(dist, gid, world)                 # [world (shard), sum of counts, k]
     d2s = _all_gather_rows(dist, d2, world)
-    mine = slice(rank * Q, (rank + 1) * Q)
+    first = sum(counts[:rank])
+    mine = slice(first, first + Q)
     return merge_topk([d2s[r, mine] for r in range(world)], [gids[r, mine] for r in range(world)], k)
 
 
@@ -244,7 +262,11 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
     per_query = {}
     for name in C_.NAMES:
         a = np.asarray(local[name])
-        a = a.reshape(len(a), -1).astype(np.float64 if a.dtype != np.float32 else np.float32)
+        # explicit width and a wire type fixed by NAME: a rank without queries (Q < world, or an empty balanced shard)
+        # holds 0-size arrays -- reshape(0, -1) of those is an error, and a type taken from the data would differ from
+        # its peers' (the rank would die before, or mis-pair in, the collective the others wait in)
+        wire = np.float32 if C_.DTYPES[name] == np.float32 else np.float64
+        a = a.reshape(len(a), 16 if name.startswith("Ts_est") else 1).astype(wire)
         t = torch.from_numpy(np.ascontiguousarray(a))
         parts = _all_gather_padded(dist, t.cuda() if dist.get_backend() == "nccl" else t, q_max, world)
         full = torch.cat([parts[r][: len(qshards[r])] for r in range(world)]).cpu().numpy()[order]
@@ -253,7 +275,7 @@ def run_eval_sharded(pipe, dist, rank, world, catalog, queries, best_match, tabl
         elif name == "sym_ransac_success":
             per_query[name] = full[:, 0] != 0
         else:
-            per_query[name] = full[:, 0]
+            per_query[name] = full[:, 0].astype(C_.DTYPES[name])
     if rank == 0 and cache_dir is not None:
         C_.save_results(cache_dir, category, register_top1, per_query)
     return H.finish_eval(stat, per_query, False)
