@@ -80,6 +80,12 @@ struct ProfScope {
 
 // adds work units to a family without bracketing a launch (the units of a launch enqueued earlier)
 void prof_add_units(const char* name, double units);
+// the same for units whose launch was bracketed in profile epoch `epoch` (cs_prof_reset starts a new one): dropped when the
+// profile has been reset since, accepted also after cs_prof_enable(0) (the region they belong to has only been CLOSED)
+void prof_add_units_epoch(const char* name, double units, uint64_t epoch);
+uint64_t prof_epoch();
+// kernel maps that still hold deferred convolution work units hand them over (cs_prof_enable(0), cs_prof_get_units)
+void kernelmap_flush_prof();
 // A second, lowest-priority stream of the calling thread (created on first use, lives as long as the
 // process) for work that may overlap the caller's stream; nullptr if it cannot be created.
 hipStream_t side_stream(int which = 0);
@@ -172,8 +178,10 @@ struct cs_kernelmap {
   // (2 Cin Cout each); turned into work units when the count is known (kernelmap_pairs / cs_kernelmap_free) instead of
   // stalling the host in cs_conv_fwd
   double prof_flop_per_pair = 0.0;
+  uint64_t prof_epoch = 0;   // the profile epoch those deferred units were collected in (stale ones are dropped)
 };
 namespace cs {
 int64_t kernelmap_pairs(const cs_kernelmap* km);
+void kernelmap_defer_prof(cs_kernelmap* km, double per_pair);
 bool prof_enabled();
 }

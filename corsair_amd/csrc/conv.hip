@@ -1164,7 +1164,7 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     else if (km->num_pairs >= 0 || !km->cnt_ready || hipEventQuery(km->cnt_ready) == hipSuccess)
       flop = per_pair * (double)kernelmap_pairs(km);
     else
-      const_cast<cs_kernelmap*>(km)->prof_flop_per_pair += per_pair;
+      kernelmap_defer_prof(const_cast<cs_kernelmap*>(km), per_pair);
   }
   ProfScope prof("conv", s, flop);
   const bool mfma_ok = (cin % 32 == 0) && (cout % 4 == 0) && (ld_in % 4 == 0) &&

@@ -482,6 +482,32 @@ static void count_slot_release(int slot) {
   g_slot_free.push_back(slot);
 }
 
+// maps holding deferred profile units (cs_conv_fwd registers, delivery / cs_kernelmap_free remove)
+static std::mutex g_prof_maps_mu;
+static std::vector<cs_kernelmap*> g_prof_maps;
+
+static void prof_maps_remove(cs_kernelmap* km) {
+  std::lock_guard<std::mutex> lk(g_prof_maps_mu);
+  for (size_t i = 0; i < g_prof_maps.size(); ++i)
+    if (g_prof_maps[i] == km) {
+      g_prof_maps[i] = g_prof_maps.back();
+      g_prof_maps.pop_back();
+      return;
+    }
+}
+
+void kernelmap_defer_prof(cs_kernelmap* km, double per_pair) {
+  const uint64_t ep = prof_epoch();
+  std::lock_guard<std::mutex> lk(g_prof_maps_mu);
+  const bool registered = km->prof_flop_per_pair > 0.0;
+  if (km->prof_epoch != ep) {      // what it still holds belongs to a region that has been reset away
+    km->prof_flop_per_pair = 0.0;
+    km->prof_epoch = ep;
+  }
+  if (!registered) g_prof_maps.push_back(km);
+  km->prof_flop_per_pair += per_pair;
+}
+
 int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
   cs_kernelmap* km = const_cast<cs_kernelmap*>(km_c);  // cached on first use
   if (!km) return -1;
@@ -490,10 +516,27 @@ int64_t kernelmap_pairs(const cs_kernelmap* km_c) {
     km->num_pairs = (int64_t)*km->h_cnt;
   }
   if (km->num_pairs >= 0 && km->prof_flop_per_pair > 0.0) {   // convolutions profiled before the count had arrived
-    prof_add_units("conv", km->prof_flop_per_pair * (double)km->num_pairs);
-    km->prof_flop_per_pair = 0.0;
+    double units = 0.0;
+    uint64_t ep = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_prof_maps_mu);
+      units = km->prof_flop_per_pair * (double)km->num_pairs;
+      ep = km->prof_epoch;
+      km->prof_flop_per_pair = 0.0;
+    }
+    prof_maps_remove(km);
+    if (units > 0.0) prof_add_units_epoch("conv", units, ep);
   }
   return km->num_pairs;
+}
+
+void kernelmap_flush_prof() {
+  std::vector<cs_kernelmap*> maps;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_maps_mu);
+    maps = g_prof_maps;
+  }
+  for (cs_kernelmap* km : maps) (void)kernelmap_pairs(km);   // waits for the count (a few microseconds behind the build)
 }
 
 // Tiling order of the convolution kernels: output rows sorted by the Gray-code RANK of their 27-bit
@@ -1278,6 +1321,7 @@ void cs_kernelmap_free(cs_kernelmap* km) {
     if (km->prof_flop_per_pair > 0.0) (void)cs::kernelmap_pairs(km);   // hands the deferred work units to the profile
     (void)hipEventDestroy(km->cnt_ready);
   }
+  if (km->prof_flop_per_pair > 0.0) cs::prof_maps_remove(km);
   count_slot_release(km->cnt_slot);
   delete km;
 }

@@ -212,6 +212,7 @@ static const char* kProfNames[] = {"conv",    "ransac_eval", "ransac_hyp", "knn"
                                    "topk",    "symcut",      "kmap",       "ransac_pre"};
 static constexpr int kNumProf = sizeof(kProfNames) / sizeof(kProfNames[0]);
 static int g_prof_on = 0;
+static std::atomic<uint64_t> g_prof_epoch{1};   // bumped by cs_prof_reset: deferred units of an older region are dropped
 static std::mutex g_prof_mu;  // calls may come from several host threads (one stream each)
 struct ProfPending {
   hipEvent_t e0, e1;
@@ -257,6 +258,16 @@ bool prof_enabled() { return g_prof_on != 0; }
 
 void prof_add_units(const char* name, double units) {
   if (!g_prof_on) return;
+  const int id = prof_id(name);
+  if (id < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_units[id] += units;
+}
+
+uint64_t prof_epoch() { return g_prof_epoch.load(); }
+
+void prof_add_units_epoch(const char* name, double units, uint64_t epoch) {
+  if (epoch != g_prof_epoch.load()) return;   // the region these units belong to has been reset away
   const int id = prof_id(name);
   if (id < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -346,10 +357,14 @@ void cs_prof_enable(int on) {
       cs::g_event_pool.push_back(e);
     }
   }
+  // closing a region: maps whose pair count was still on its way when their convolutions were bracketed deliver those
+  // units NOW -- not when Python happens to free the map, possibly inside the next leg's region
+  if (!on) cs::kernelmap_flush_prof();
   cs::g_prof_on = on;
 }
 
 void cs_prof_reset(void) {
+  cs::g_prof_epoch.fetch_add(1);
   for (int i = 0; i < cs::kNumProf; ++i) {
     cs::prof_drain(i);
     cs::g_prof_ms[i] = 0;
@@ -376,6 +391,7 @@ int cs_prof_get_units(const char* name, double* units) {
     cs::set_error("unknown profile family '%s'", name);
     return CS_ERR_INVALID;
   }
+  cs::kernelmap_flush_prof();
   if (units) *units = cs::g_prof_units[id];
   return CS_OK;
 }

@@ -9,13 +9,26 @@ from .find_nn import find_knn
 
 def find_kcorr(F0, F1, k=1, nn_max_n=500, subsample_size=-1):
     """Top-k matching pairs by local features (utils/eval_pose.py:48-79): returns
-    (np.repeat(arange(N0), k), nn_inds.flatten()).  Sub-sampling (never used on the evaluated
-    path, subsample_size=-1 at utils/symmetry.py:267,311) is not supported."""
-    if subsample_size > 0:
-        raise NotImplementedError("find_kcorr: subsample_size > 0 is not on the evaluated path")
+    (np.repeat(arange(N0), k), nn_inds.flatten()).  subsample_size > 0 and len(F0) > subsample_size (never on the
+    evaluated path: sym_pose passes -1, utils/symmetry.py:267,311): both sides are cut to at most `subsample_size` rows
+    drawn WITHOUT replacement from NumPy's global generator, F0's draw first -- the reference's two `np.random.choice`
+    calls, so a caller that seeds `np.random` gets the reference's rows -- and the pair indices refer to the full sets."""
+    sub = subsample_size > 0 and len(F0) > subsample_size
+    if sub:
+        inds0 = np.random.choice(len(F0), min(len(F0), subsample_size), replace=False)
+        inds1 = np.random.choice(len(F1), min(len(F1), subsample_size), replace=False)
+        if torch.is_tensor(F0):
+            F0 = F0[torch.from_numpy(inds0).to(F0.device)]
+        else:
+            F0 = np.asarray(F0)[inds0]
+        if torch.is_tensor(F1):
+            F1 = F1[torch.from_numpy(inds1).to(F1.device)]
+        else:
+            F1 = np.asarray(F1)[inds1]
     nn_inds = find_knn(F0, F1, k).reshape(-1)
-    inds0 = np.repeat(np.arange(len(F0)), k)
-    return inds0, nn_inds
+    if sub:
+        return np.repeat(inds0, k), inds1[nn_inds]
+    return np.repeat(np.arange(len(F0)), k), nn_inds
 
 
 def registration_based_on_corr(source_pcd, target_pcd, max_corr_dist=0.03, seed=0,

@@ -14,9 +14,20 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "corsair_oracle.c")
 BUILD_DIR = os.path.join(_HERE, "_build")
-LIB = os.path.join(BUILD_DIR, "libcorsair_oracle.so")
+# ORACLE_SANITIZE=1: the AddressSanitizer + UndefinedBehaviorSanitizer build of the same source (CPU only,
+# never on the GPU box).  The C oracle is the arbiter of every parity test and is 800 lines of hand-rolled index
+# arithmetic: tests/test_oracle_sanitized_cpu.py re-runs the oracle's CPU tests on this build in a child interpreter
+# started with LD_PRELOAD=libasan (an instrumented .so cannot be loaded into an uninstrumented python otherwise).
+SANITIZE = os.environ.get("ORACLE_SANITIZE", "0") == "1"
+LIB = os.path.join(BUILD_DIR, "libcorsair_oracle_san.so" if SANITIZE else "libcorsair_oracle.so")
+SAN_FLAGS = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
 
 _lib = None
+
+
+def sanitizer_runtime():
+    """Path of gcc's libasan.so (what the child interpreter preloads)."""
+    return subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
 
 
 def build(force=False):
@@ -24,8 +35,9 @@ def build(force=False):
     newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(_HERE, "kmeans_draws.h")))
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
-    cmd = ["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC",
-           "-std=c11", "-I", _HERE, SRC, "-o", LIB, "-lm"]
+    opt = SAN_FLAGS if SANITIZE else ["-O3"]
+    cmd = ["gcc"] + opt + ["-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC",
+                           "-std=c11", "-I", _HERE, SRC, "-o", LIB, "-lm"]
     subprocess.check_call(cmd)
     return LIB
 
