@@ -163,10 +163,8 @@ struct cs_kernelmap {
   int transposed = 0;
   int32_t* d_nbr = nullptr;      // [n_out, kvol]
   int32_t* d_rowlist = nullptr;  // [n_out] output rows ordered by neighbour-presence mask (tiling order)
-  // the same table in tiling order, so that a convolution tile reads its neighbour rows with offsets that do
-  // not depend on a load (nbr_sorted[t][k] = nbr[rowlist[t]][k]), and the offsets present in every group of
-  // 32 consecutive rows of that order (padded with zeros to a multiple of 8 groups)
-  int32_t* d_nbr_sorted = nullptr;   // [n_out, kvol]; absent neighbours stored as row n_in (one past the input)
+  // the offsets present in every group of 32 consecutive rows of the tiling order (padded with zeros to a multiple of 8
+  // groups); the convolution reads `d_nbr` through `d_rowlist` (round 5: no copy of the table in tiling order)
   uint32_t* d_gmask = nullptr;       // [ceil(n_out / 32) rounded up to 8]
   // Pair count: written by the build kernels, copied to a page-locked slot behind them; resolved on
   // first use (kernelmap_pairs) so that building a map does not stall the host.

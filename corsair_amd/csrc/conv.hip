@@ -305,10 +305,11 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   const int cchunks = cin / 32;
 
   // ---- rows of this wave's group, offsets they use ----
-  // `nbr` is the neighbour table IN TILING ORDER (cs_kernelmap::d_nbr_sorted: row t of it belongs to output
-  // row rowlist[t]) and `gmask` the offsets present in every 32-row group of that order, both made when the map
-  // is built: nothing in front of the first DMA depends on a vector load (the group masks are scalar loads; the
-  // output rows are only needed by the epilogue).  GATHER = false (1x1): row t is output row t, one "offset".
+  // `nbr` is the neighbour table in OUTPUT-ROW order (cs_kernelmap::d_nbr, absent = -1), `rowlist` the tiling order
+  // (tile slot t holds output row rowlist[t]) and `gmask` the offsets present in every 32-row group of that order,
+  // made when the map is built.  Round 5: the copy of the table in tiling order (216 B per map row written and read
+  // once per forward, 0.24 ms per stress forward) is gone -- a tile's 32 rows are 32 separate 108-byte segments either
+  // way, the row index costs one load per tile.  GATHER = false (1x1): row t is output row t, one "offset".
   // lane (rl, half): output row of group slot rl; both halves hold the same row
   int32_t my_o = -1;
   {
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
     const int64_t t = row0 + rg * 32 + r;
     a_row_ok[i] = t < n_out;
-    a_nbr_off[i] = GATHER ? (unsigned)(t < n_out ? t : 0) * (unsigned)kvol * 4u : (unsigned)(t < n_out ? t : 0);
+    // GATHER: byte offset of row rowlist[t] of the neighbour table (the table is in OUTPUT-ROW order, the tile in tiling
+    // order: the row index comes from the lane of this wave that holds tile slot r, loaded above as my_o)
+    const int32_t o_r = __shfl(my_o, r);
+    a_nbr_off[i] = GATHER ? (unsigned)(o_r >= 0 ? o_r : 0) * (unsigned)kvol * 4u : (unsigned)(t < n_out ? t : 0);
     a_c4b[i] = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
   }
   unsigned b_voff[B_PIECES];      // byte offset of this lane's 16 bytes inside the slab of (k, cc)
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   const i32x4 srd_a = make_srd(in, in_bytes);
   const i32x4 srd_b = make_srd(w + n0, w_bytes - (unsigned)n0 * 4u);
   const unsigned ld_in_b = (unsigned)ld_in * 4u;
+  const unsigned absent_row = in_bytes / ld_in_b;          // = n_in (in_bytes = n_in * ld_in * 4)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   const unsigned a_lds = lds_base + rg * 4096 + cg * A_PIECES * 1024;
   const unsigned b_lds = lds_base + C::A_BYTES + wave * 1024;
@@ -379,7 +384,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
   auto a_offsets = [&](const int32_t (&src)[A_PIECES], unsigned (&vo)[A_PIECES]) {
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i)
-      vo[i] = __umul24((unsigned)src[i], ld_in_b) + a_c4b[i];   // absent = row n_in: past the descriptor's range
+      // an absent neighbour is -1 in the table: as unsigned it clamps to row n_in, ONE PAST the input tensor, and the
+      // buffer descriptor's range check returns zeros for that row (one v_min_u32 per piece and chunk)
+      vo[i] = __umul24(GATHER ? min((unsigned)src[i], absent_row) : (unsigned)src[i], ld_in_b) + a_c4b[i];
   };
   auto b_soff = [&](int k, int cc) { return (unsigned)(((k < K_END ? k : 0) * cin + cc * 32) * cout) * 4u; };
 
@@ -694,7 +701,10 @@ __global__ __launch_bounds__(256) void k_conv_split(
   for (int i = 0; i < A_PIECES; ++i) {
     const int r = (cg * A_PIECES + i) * 8 + (lane >> 3);
     const int64_t t = row0 + rg * 32 + r;
-    a_nbr_off[i] = GATHER ? (unsigned)(t < n_out ? t : 0) * (unsigned)kvol * 4u : (unsigned)(t < n_out ? t : 0);
+    // GATHER: byte offset of row rowlist[t] of the neighbour table (the table is in OUTPUT-ROW order, the tile in tiling
+    // order: the row index comes from the lane of this wave that holds tile slot r, loaded above as my_o)
+    const int32_t o_r = __shfl(my_o, r);
+    a_nbr_off[i] = GATHER ? (unsigned)(o_r >= 0 ? o_r : 0) * (unsigned)kvol * 4u : (unsigned)(t < n_out ? t : 0);
     a_c4b[i] = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
   }
   // weight stage = [SEGS][TN][16 B], linear in 16-B units u = piece * 64 + lane: segment u / TN, column u % TN
@@ -708,6 +718,7 @@ __global__ __launch_bounds__(256) void k_conv_split(
   const i32x4 srd_a = make_srd(in, in_bytes);
   const i32x4 srd_b = make_srd(wq + (size_t)n0 * 8, wq_bytes - (unsigned)n0 * 16u);
   const unsigned ld_in_b = (unsigned)ld_in * 4u;
+  const unsigned absent_row = in_bytes / ld_in_b;          // = n_in (in_bytes = n_in * ld_in * 4)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   const unsigned a_lds = lds_base + rg * 4096 + cg * A_PIECES * 1024;
   const unsigned b_lds = lds_base + A_BYTES + wave * 1024;
@@ -732,7 +743,8 @@ __global__ __launch_bounds__(256) void k_conv_split(
     if ((mymask >> k) & 1u) {
 #pragma unroll
       for (int i = 0; i < A_PIECES; ++i)
-        buf_dma16(__umul24((unsigned)src[i], ld_in_b) + a_c4b[i], srd_a, a_so, a_lds + b * STAGE_BYTES + i * 1024);
+        buf_dma16(__umul24(GATHER ? min((unsigned)src[i], absent_row) : (unsigned)src[i], ld_in_b) + a_c4b[i], srd_a, a_so,
+                  a_lds + b * STAGE_BYTES + i * 1024);
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j)
@@ -1137,7 +1149,7 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
   int kvol = 1;
   const int32_t* nbr = nullptr;
   const int32_t* rowlist = nullptr;
-  const int32_t* nbr_t = nullptr;     // neighbour table in tiling order + group masks (k_conv_dma)
+  const int32_t* nbr_t = nullptr;     // neighbour table (row order) when the tiling order + group masks exist (k_conv_dma)
   const uint32_t* gmask = nullptr;
   if (km) {
     CS_REQUIRE(km->n_out == n_out && km->n_in == n_in, CS_ERR_INVALID,
@@ -1146,7 +1158,7 @@ int cs_conv_fwd(const cs_kernelmap* km, int64_t n_in, int64_t n_out, const float
     kvol = km->kvol;
     nbr = km->d_nbr;
     rowlist = km->d_rowlist;
-    nbr_t = km->d_nbr_sorted;
+    nbr_t = (km->d_rowlist && km->d_gmask) ? km->d_nbr : nullptr;
     gmask = km->d_gmask;
   } else {
     CS_REQUIRE(n_in == n_out, CS_ERR_INVALID, "cs_conv_fwd: 1x1 conv needs n_in == n_out");

@@ -346,43 +346,8 @@ __global__ __launch_bounds__(NT) void k_build_nbr_lds(
   if ((tid & 63) == 0 && found_total) atomicAdd(pair_count, (unsigned long long)found_total);
 }
 
-// Per-sample segment table of a coordinate map (computed once, cached on the map).
-static int ensure_segments(cs_coordmap* m, hipStream_t s) {
-  if (m->seg_state != 0) return CS_OK;
-  m->seg_state = -1;  // unavailable unless everything below succeeds
-  if (m->n == 0) return CS_OK;
-  int32_t last_b = -1;
-  CS_HIP_CHECK(download_async(&last_b, m->d_coords + 4 * (m->n - 1), sizeof(int32_t), s));
-  CS_HIP_CHECK(download_sync(s));
-  if (last_b < 0 || last_b >= 65536) return CS_OK;
-  const int nb = last_b + 1;
-  int32_t* seg = (int32_t*)pool_alloc((size_t)(nb + 1) * sizeof(int32_t));
-  PoolBuf<int> flags(2);
-  if (!seg || !flags.p) {
-    pool_free(seg);
-    return CS_OK;
-  }
-  int h_flags[2] = {0, 0};
-  CS_HIP_CHECK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  CS_HIP_CHECK(hipMemsetAsync(seg, 0, (size_t)(nb + 1) * sizeof(int32_t), s));
-  hipLaunchKernelGGL(k_segments, dim3((unsigned)ceil_div(m->n, 256)), dim3(256), 0, s, m->d_coords,
-                     m->n, nb, seg, flags.p);
-  hipLaunchKernelGGL(k_segment_max, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, s, seg, nb,
-                     flags.p);
-  CS_HIP_CHECK(download_async(h_flags, flags.p, sizeof(h_flags), s));
-  CS_HIP_CHECK(download_sync(s));
-  if (h_flags[0]) {
-    pool_free(seg);
-    return CS_OK;  // not grouped by sample: global path
-  }
-  m->d_seg = seg;
-  m->n_batch = nb;
-  m->max_seg = h_flags[1];
-  m->seg_state = 1;
-  return CS_OK;
-}
-
-// The same for several maps at once: TWO host round trips in total (last batch index of every map; the grouping
+// Per-sample segment tables of coordinate maps (computed once, cached on the map): for several maps at once --
+// TWO host round trips in total (last batch index of every map; the grouping
 // flags of every map) instead of two per map -- the four coordinate maps of a ResUNet batch cost eight otherwise.
 static int ensure_segments_many(cs_coordmap* const* maps, int n, hipStream_t s) {
   std::vector<cs_coordmap*> todo;
@@ -546,88 +511,6 @@ void kernelmap_flush_prof() {
 // group at strides 1 / 2 / 4: Gray rank 1.41 / 1.19 / 1.28, plain numeric order 1.48 / 1.20 / 1.29, the
 // 12-bit grouping of rounds 1-2 2.05 / 1.59 / 1.52).  The order inside equal keys is the radix sort's
 // (stable: row order); every output row is computed independently, results do not depend on the order.
-__global__ __launch_bounds__(256) void k_row_keys(const int32_t* __restrict__ nbr, int64_t n_out, int kvol,
-                                                  uint32_t* __restrict__ key, int32_t* __restrict__ row,
-                                                  const unsigned long long* __restrict__ d_cnt,
-                                                  unsigned long long* host_cnt) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // the pair count of the build kernels in front of this one goes to its page-locked slot from here (a
-  // device -> host copy of 8 bytes was one blit-kernel launch per map)
-  if (o == 0 && host_cnt) __hip_atomic_store(host_cnt, *d_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (o >= n_out) return;
-  uint32_t m = 0;
-  for (int k = 0; k < kvol; ++k) m |= (nbr[o * kvol + k] >= 0 ? 1u : 0u) << k;
-  // inverse Gray code: r with r ^ (r >> 1) == m
-  m ^= m >> 1;
-  m ^= m >> 2;
-  m ^= m >> 4;
-  m ^= m >> 8;
-  m ^= m >> 16;
-  key[o] = m;
-  row[o] = (int32_t)o;
-}
-
-// Row order of a SMALL map (<= SORT_SMALL_MAX rows: the coarsest level of a batch) in one launch: bitonic sort
-// of (key << 32 | row) in LDS by one workgroup.  hipcub's radix sort takes a block-sort + merge path of 5 - 8
-// launches for such sizes (55 launches per chair step over the ten maps of a batch).  Any order of equal keys
-// is fine for the convolution; (key, row) pairs are distinct, so the result is also deterministic.
-constexpr int SORT_SMALL_MAX = 4096;   // (16 384 rows take one workgroup 150 us: hipcub wins from ~8 k rows on)
-__global__ __launch_bounds__(1024) void k_sort_small(const uint32_t* __restrict__ key, int n, int npow2,
-                                                     uint32_t* __restrict__ key_sorted, int32_t* __restrict__ rowlist) {
-  extern __shared__ unsigned long long sk[];
-  for (int i = threadIdx.x; i < npow2; i += 1024)
-    sk[i] = i < n ? ((unsigned long long)key[i] << 32) | (unsigned)i : ~0ULL;
-  __syncthreads();
-  for (int size = 2; size <= npow2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < (npow2 >> 1); t += 1024) {
-        const int lo = 2 * t - (t & (stride - 1));      // index of the lower element of pair t
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = sk[lo], b = sk[hi];
-        if ((a > b) == up) {
-          sk[lo] = b;
-          sk[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    key_sorted[i] = (uint32_t)(sk[i] >> 32);
-    rowlist[i] = (int32_t)(sk[i] & 0xffffffffu);
-  }
-}
-
-// the neighbour table in tiling order + the offsets every 32-row group of that order uses (one thread per
-// table element; the group masks come from the sorted keys: mask = Gray code of the rank)
-__global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowlist,
-                                                       const uint32_t* __restrict__ key_sorted, int64_t n_out, int kvol,
-                                                       int32_t* __restrict__ nbr_sorted, uint32_t* __restrict__ gmask,
-                                                       int64_t n_groups_padded, int32_t absent) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < n_out * kvol) {
-    const int64_t t = e / kvol;
-    const int k = (int)(e - t * kvol);
-    // an absent neighbour is stored as row `absent` = n_in, ONE PAST the input tensor: the convolution turns entries
-    // into byte offsets with one multiply-add and the buffer descriptor's range check returns zeros for that row
-    const int32_t v = nbr[(int64_t)rowlist[t] * kvol + k];
-    nbr_sorted[e] = v < 0 ? absent : v;
-  }
-  if (e < n_groups_padded) {
-    uint32_t m = 0;
-    for (int r = 0; r < 32; ++r) {
-      const int64_t t = e * 32 + r;
-      if (t < n_out) {
-        const uint32_t rank = key_sorted[t];
-        m |= rank ^ (rank >> 1);
-      }
-    }
-    gmask[e] = m;
-  }
-}
-
-// export helpers: element t = k * n_out + o of the k-major view
 // ---- the tiling order of ALL kernel maps of a batch in one pass (round 4) ---------------------------------------------
 // Ten maps of a batch used to mean ten row-key launches, ten device sorts (5 - 20 launches each: hipcub takes a block-sort +
 // merge path for the mid-size maps) and ten table launches: 115 launches per stress batch, 60 per chair batch, bound by
@@ -637,51 +520,51 @@ __global__ __launch_bounds__(256) void k_sorted_tables(const int32_t* __restrict
 constexpr int ORDER_MAX_MAPS = 16;
 struct OrderMap {
   const int32_t* nbr;
-  int32_t* nbr_sorted;
   uint32_t* gmask;
   int32_t* rowlist;
   const unsigned long long* d_cnt;
   unsigned long long* host_cnt;
   int64_t n_out, base, n_groups;
-  int32_t absent;
-  uint32_t kblk0, tblk0;   // first workgroup of this map in the key / table launch
+  uint32_t kblk0, tblk0;   // first workgroup of this map in the key / finish launch
+  uint32_t tag;            // map index << 27: the sort keeps every map's rows together, in the order of `base`
+  int need_keys;           // 1: k_row_keys_all computes this map's keys from its table (maps the level kernel did not build)
 };
 struct OrderTab {
   int n;
   OrderMap m[ORDER_MAX_MAPS];
 };
+__device__ __forceinline__ uint32_t gray_rank(uint32_t m) {   // r with r ^ (r >> 1) == m
+  m ^= m >> 1;
+  m ^= m >> 2;
+  m ^= m >> 4;
+  m ^= m >> 8;
+  m ^= m >> 16;
+  return m;
+}
 __global__ __launch_bounds__(256) void k_row_keys_all(const OrderTab tab, uint32_t* __restrict__ key,
                                                       int32_t* __restrict__ row) {
   int i = 0;
   while (i + 1 < tab.n && blockIdx.x >= tab.m[i + 1].kblk0) ++i;
   const OrderMap& mp = tab.m[i];
+  if (!mp.need_keys) return;
   const int64_t o = (int64_t)(blockIdx.x - mp.kblk0) * 256 + threadIdx.x;
-  if (o == 0 && mp.host_cnt) __hip_atomic_store(mp.host_cnt, *mp.d_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (o >= mp.n_out) return;
   uint32_t m = 0;
   for (int k = 0; k < 27; ++k) m |= (mp.nbr[o * 27 + k] >= 0 ? 1u : 0u) << k;
-  m ^= m >> 1;   // inverse Gray code (see k_row_keys)
-  m ^= m >> 2;
-  m ^= m >> 4;
-  m ^= m >> 8;
-  m ^= m >> 16;
-  key[mp.base + o] = ((uint32_t)i << 27) | m;
+  key[mp.base + o] = mp.tag | gray_rank(m);
   row[mp.base + o] = (int32_t)o;
 }
-__global__ __launch_bounds__(256) void k_sorted_tables_all(const OrderTab tab, const uint32_t* __restrict__ key_sorted,
-                                                           const int32_t* __restrict__ row_sorted) {
+// behind the sort: every map's row list (its slice of the sorted payload), the group masks, and the pair count of the
+// build kernels handed to its page-locked slot (a device -> host copy of 8 bytes was one blit-kernel launch per map)
+__global__ __launch_bounds__(256) void k_order_finish(const OrderTab tab, const uint32_t* __restrict__ key_sorted,
+                                                      const int32_t* __restrict__ row_sorted) {
   int i = 0;
   while (i + 1 < tab.n && blockIdx.x >= tab.m[i + 1].tblk0) ++i;
   const OrderMap& mp = tab.m[i];
   const int64_t e = (int64_t)(blockIdx.x - mp.tblk0) * 256 + threadIdx.x;
+  if (e == 0 && mp.host_cnt) __hip_atomic_store(mp.host_cnt, *mp.d_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int32_t* rl = row_sorted + mp.base;
   const uint32_t* ks = key_sorted + mp.base;
-  if (e < mp.n_out * 27) {
-    const int64_t t = e / 27;
-    const int k = (int)(e - t * 27);
-    const int32_t v = mp.nbr[(int64_t)rl[t] * 27 + k];
-    mp.nbr_sorted[e] = v < 0 ? mp.absent : v;
-  }
   if (e < mp.n_out) mp.rowlist[e] = rl[e];
   if (e < mp.n_groups) {
     uint32_t m = 0;
@@ -693,6 +576,244 @@ __global__ __launch_bounds__(256) void k_sorted_tables_all(const OrderTab tab, c
       }
     }
     mp.gmask[e] = m;
+  }
+}
+
+// ---- every kernel map that probes ONE coordinate level, in one launch (round 5) ---------------------------------------
+// The ten maps of a ResUNet batch probe four tables: level L serves L -> L (submanifold), L -> 2L (strided: output rows of
+// level 2L look for level-L rows) and the transposed 2L' -> L' map whose INPUT is level L (output rows of the finer level
+// look for level-L rows).  Round 4 launched one kernel per map, every slice of every launch re-inserting its sample into LDS
+// (2.2 ms of kernel-map work per batch-64 stress forward, 40 - 48 % of the convolutions' time).  Here a
+// workgroup (slice x, sample b) builds the sample's table ONCE and answers the probes of all jobs from it:
+//   * the sample's coordinates are read once (16-byte loads, held in registers for the bounding box AND the insert);
+//   * a thread owns one (row, offset) with 32 lanes per row (27 used): the 27 results of a row are one contiguous 108-byte
+//     store, the row's presence mask is one ballot -- so the tiling key (Gray rank of the mask) and the pair count come out
+//     of the builder and nothing has to read the table again (k_row_keys_all re-read 108 B per row);
+//   * coordinates of the next four rows of a thread are requested before the first is probed (the probe loop was a chain
+//     of dependent global load -> LDS probe -> store per entry, with four waves per SIMD to hide it);
+//   * a sample that does not fit the LDS table (too many rows, bounding box wider than 1023 cells) is probed in the level's
+//     GLOBAL table by the same workgroup -- no flag array, no second launch that usually does nothing.
+constexpr int LEVEL_MAX_JOBS = 4;
+struct LevelJob {
+  const int32_t* out_coords;   // [n_out,4] rows grouped by sample
+  const int32_t* out_seg;      // [n_batch + 1]
+  int32_t* nbr;                // [n_out,27]
+  uint32_t* key;               // tiling keys / row payload of this map inside the batch's sort arrays (nullptr: not wanted)
+  int32_t* row;
+  unsigned long long* cnt;     // pair counter
+  int step, sign;
+  uint32_t tag;                // map index << 27
+};
+struct LevelArgs {
+  int n_jobs;
+  LevelJob job[LEVEL_MAX_JOBS];
+  const int32_t* in_coords;
+  const int32_t* in_seg;
+  int unit, ushift;
+  const uint64_t* gkeys;       // the level's global table (cs_coordmap): oversized samples
+  const int32_t* gvals;
+  uint64_t gmask;
+  unsigned long long* trace;   // CS_KMAP_TRACE=1: [workgroup][8] phase stamps (100 MHz), else nullptr
+};
+
+template <int SLOTS, int NT>
+__global__ __launch_bounds__(NT) void k_level_maps(const LevelArgs a) {
+  // The table: NB buckets of four 4-byte keys (one ds_read_b128 fetches a bucket) + four 2-byte local rows.  A key goes into
+  // the first free slot of its bucket, slots fill in order, a full bucket spills into the next one.  A probe reads ONE
+  // bucket and is done unless that bucket is full and does not hold the key (6 % of the probes at the usual load of 1.5
+  // keys per bucket) -- so the first reads of several probes can be in flight together: the round-4 kernels chased one
+  // linear-probing chain per lane with four waves per SIMD to hide it, and were bound by that latency (trace: 142 us of
+  // probes against 22 us of table build per stride-1 level of a stress batch).
+  constexpr int NB = SLOTS / 4;
+  constexpr int MAX_ROWS = SLOTS / 8 * 5;            // load factor <= 0.625 (2.5 keys per bucket)
+  constexpr int RPT = (MAX_ROWS + NT - 1) / NT;      // in-rows a thread holds in registers
+  constexpr int ROWS_PER_PASS = NT / 32;             // output rows a workgroup probes at a time
+  constexpr int U = 8;                               // probes a lane keeps in flight
+  __shared__ __attribute__((aligned(16))) uint32_t keys[SLOTS];
+  __shared__ __attribute__((aligned(8))) uint16_t vals[SLOTS];
+  __shared__ int bmin[3], bmax[3];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int i0 = a.in_seg[b], i1 = a.in_seg[b + 1];
+  const int n_in = i1 - i0;
+  // rows of this slice per job; a workgroup without any leaves before the first barrier
+  auto slice = [&](int j, int& lo_, int& hi_) {
+    const int o0 = a.job[j].out_seg[b], o1 = a.job[j].out_seg[b + 1];
+    const int per = (o1 - o0 + (int)gridDim.x - 1) / (int)gridDim.x;
+    lo_ = o0 + (int)blockIdx.x * per;
+    hi_ = min(o1, lo_ + per);
+  };
+  bool any = false;
+  for (int j = 0; j < a.n_jobs; ++j) {
+    int lo_, hi_;
+    slice(j, lo_, hi_);
+    any = any || lo_ < hi_;
+  }
+  if (!any) return;
+  unsigned long long* tr = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+  const int ushift = a.ushift, unit = a.unit;
+  auto udiv = [&](int v) { return ushift >= 0 ? v >> ushift : v / unit; };          // v >= 0
+  auto umult = [&](int v) { return ushift >= 0 ? (v & (unit - 1)) == 0 : v % unit == 0; };
+  auto bucket_of = [&](uint32_t key) { return __umulhi(key * 2654435761u, (uint32_t)NB); };   // [0, NB)
+
+  bool use_lds = n_in <= MAX_ROWS;                   // workgroup-uniform
+  int4 c[RPT];
+  if (use_lds) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int i = i0 + tid + j * NT;
+      c[j] = make_int4(0, 0, 0, 0);
+      if (i < i1) c[j] = reinterpret_cast<const int4*>(a.in_coords)[i];
+    }
+    if (tid < 3) {
+      bmin[tid] = 0x7fffffff;
+      bmax[tid] = -0x7fffffff;
+    }
+    for (int i = tid; i < NB; i += NT)
+      reinterpret_cast<uint4*>(keys)[i] = make_uint4(LDS_EMPTY, LDS_EMPTY, LDS_EMPTY, LDS_EMPTY);
+    __syncthreads();
+    // bounding box: per thread (registers), per wave (shuffles), one LDS atomic per wave and axis
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      if (i0 + tid + j * NT < i1) {
+        lo[0] = min(lo[0], c[j].y);
+        hi[0] = max(hi[0], c[j].y);
+        lo[1] = min(lo[1], c[j].z);
+        hi[1] = max(hi[1], c[j].z);
+        lo[2] = min(lo[2], c[j].w);
+        hi[2] = max(hi[2], c[j].w);
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo[ax] = min(lo[ax], __shfl_xor(lo[ax], off));
+        hi[ax] = max(hi[ax], __shfl_xor(hi[ax], off));
+      }
+      if ((tid & 63) == 0) {
+        atomicMin(&bmin[ax], lo[ax]);
+        atomicMax(&bmax[ax], hi[ax]);
+      }
+    }
+    __syncthreads();
+  }
+  int mx = 0, my = 0, mz = 0, ex = -1, ey = -1, ez = -1;   // an empty sample: no cell is inside the box
+  if (use_lds && n_in > 0) {
+    mx = bmin[0];
+    my = bmin[1];
+    mz = bmin[2];
+    ex = udiv(bmax[0] - mx);
+    ey = udiv(bmax[1] - my);
+    ez = udiv(bmax[2] - mz);
+    if (ex > 1023 || ey > 1023 || ez > 1023) use_lds = false;   // (uniform: every thread reads the same box)
+  }
+  if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
+  if (use_lds) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int i = i0 + tid + j * NT;
+      if (i < i1) {
+        const uint32_t key = (uint32_t)udiv(c[j].y - mx) | ((uint32_t)udiv(c[j].z - my) << 10) |
+                             ((uint32_t)udiv(c[j].w - mz) << 20);
+        uint32_t slot = bucket_of(key) * 4u;   // coordinates are unique inside a map: every key claims its own slot
+        while (atomicCAS(&keys[slot], LDS_EMPTY, key) != LDS_EMPTY) slot = slot + 1 == SLOTS ? 0 : slot + 1;
+        vals[slot] = (uint16_t)(i - i0);
+      }
+    }
+    __syncthreads();
+  }
+  if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
+
+  const int k = tid & 31;                             // offset of this lane; lanes 27..31 of a row idle
+  const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+  const int sh = tid & 32;                            // this row's half of the wave ballot
+#pragma unroll 1
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const LevelJob& J = a.job[j];
+    const int ox = J.sign * dx * J.step - mx, oy = J.sign * dy * J.step - my, oz = J.sign * dz * J.step - mz;
+    const int4* oc = reinterpret_cast<const int4*>(J.out_coords);
+    int32_t* const nbr = J.nbr;
+    uint32_t* const jkey = J.key;
+    int32_t* const jrow = J.row;
+    const uint32_t tag = J.tag;
+    int found = 0;
+    int s0j, s1j;
+    slice(j, s0j, s1j);
+    // the row's mask is a ballot, its tiling key and row payload come from the lane of offset 0
+    auto emit = [&](int o, int32_t v) {
+      if (k < 27) nbr[(int64_t)o * 27 + k] = v;
+      const uint32_t m = (uint32_t)(__ballot(v >= 0) >> sh) & 0x7ffffffu;
+      if (k == 0) {
+        found += __popc(m);
+        if (jkey) {
+          jkey[o] = tag | gray_rank(m);
+          jrow[o] = o;
+        }
+      }
+    };
+    if (use_lds) {
+      for (int ob = s0j + (tid >> 5); ob < s1j; ob += U * ROWS_PER_PASS) {
+        int4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int o = ob + u * ROWS_PER_PASS;
+          p[u] = make_int4(0, 0, 0, 0);
+          if (o < s1j) p[u] = oc[o];
+        }
+        uint32_t key[U], bk[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int x = p[u].y + ox, y = p[u].z + oy, z = p[u].w + oz;      // relative to the box corner
+          const int cx = udiv(max(x, 0)), cy = udiv(max(y, 0)), cz = udiv(max(z, 0));
+          live[u] = k < 27 && ob + u * ROWS_PER_PASS < s1j && (x | y | z) >= 0 && umult(x) && umult(y) && umult(z) &&
+                    cx <= ex && cy <= ey && cz <= ez;
+          key[u] = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
+          bk[u] = live[u] ? bucket_of(key[u]) : 0u;
+        }
+        uint4 K[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) K[u] = reinterpret_cast<const uint4*>(keys)[bk[u]];   // U reads in flight
+        int32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int sl = K[u].x == key[u] ? 0 : K[u].y == key[u] ? 1 : K[u].z == key[u] ? 2 : K[u].w == key[u] ? 3 : -1;
+          uint32_t bb = bk[u];
+          if (live[u] && sl < 0 && K[u].w != LDS_EMPTY) {     // full bucket without the key: it may have spilled on
+            while (true) {
+              bb = bb + 1 == NB ? 0 : bb + 1;
+              const uint4 Kn = reinterpret_cast<const uint4*>(keys)[bb];
+              sl = Kn.x == key[u] ? 0 : Kn.y == key[u] ? 1 : Kn.z == key[u] ? 2 : Kn.w == key[u] ? 3 : -1;
+              if (sl >= 0 || Kn.w == LDS_EMPTY) break;
+            }
+          }
+          v[u] = (live[u] && sl >= 0) ? i0 + (int32_t)vals[bb * 4 + sl] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int o = ob + u * ROWS_PER_PASS;
+          if (o < s1j) emit(o, v[u]);
+        }
+      }
+    } else {
+      // a sample too large or too wide for the LDS table: the same probes in the level's global table
+      for (int o = s0j + (tid >> 5); o < s1j; o += ROWS_PER_PASS) {
+        const int4 pp = oc[o];
+        int32_t v = -1;
+        if (k < 27) {
+          const int X = pp.y + ox + mx, Y = pp.z + oy + my, Z = pp.w + oz + mz;
+          if (coord_in_range(pp.x, X, Y, Z)) v = hash_lookup(a.gkeys, a.gvals, a.gmask, pack_key(pp.x, X, Y, Z));
+        }
+        emit(o, v);
+      }
+    }
+    // pair count: wave reduce, one atomic per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) found += __shfl_xor(found, off);
+    if ((tid & 63) == 0 && found) atomicAdd(J.cnt, (unsigned long long)found);
+    if (tr && tid == 0) tr[3 + j] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -911,282 +1032,241 @@ void cs_coordmap_free(cs_coordmap* m) {
 
 }  // extern "C"
 
-// one kernel map on stream `s` (the caller has announced its stream to the pool)
-// defer_order: leave the tiling order (row list, sorted table, group masks) and the pair-count hand-over to
-// order_many(), which does them for all maps of a batch at once; *d_cnt_out then receives the device counter
-// (scratch of this call: valid until the caller ends its pool deferral)
-static int kernelmap_build_on(const cs_coordmap* in, const cs_coordmap* out, int kernel_size, int transposed,
-                              hipStream_t s, cs_kernelmap** km_out, bool defer_order = false,
-                              const unsigned long long** d_cnt_out = nullptr) {
-  CS_REQUIRE(in && out && km_out, CS_ERR_INVALID, "cs_kernelmap_build: NULL argument");
-  *km_out = nullptr;
+// ---- building the kernel maps of a batch -------------------------------------------------------------------------------
+// Geometry of one map: which way the probes go.  Plain: out row at p looks for in rows at p + d * step (step = the in
+// map's tensor stride); transposed (in = the coarser map): p - d * step with step = the out map's stride.
+static int map_geometry(const cs_coordmap* in, const cs_coordmap* out, int kernel_size, int transposed, int* step, int* sign) {
+  CS_REQUIRE(in && out, CS_ERR_INVALID, "cs_kernelmap_build: NULL argument");
   CS_REQUIRE(kernel_size == 3 || kernel_size == 1, CS_ERR_UNSUPPORTED,
              "cs_kernelmap_build: kernel_size %d not supported (1 or 3)", kernel_size);
-  int step, sign;
   if (!transposed) {
-    CS_REQUIRE(out->tensor_stride == in->tensor_stride ||
-                   out->tensor_stride == 2 * in->tensor_stride,
-               CS_ERR_INVALID, "cs_kernelmap_build: tensor strides %d -> %d not supported",
-               in->tensor_stride, out->tensor_stride);
-    step = in->tensor_stride;
-    sign = +1;
+    CS_REQUIRE(out->tensor_stride == in->tensor_stride || out->tensor_stride == 2 * in->tensor_stride, CS_ERR_INVALID,
+               "cs_kernelmap_build: tensor strides %d -> %d not supported", in->tensor_stride, out->tensor_stride);
+    *step = in->tensor_stride;
+    *sign = +1;
   } else {
     CS_REQUIRE(in->tensor_stride == 2 * out->tensor_stride, CS_ERR_INVALID,
-               "cs_kernelmap_build: transposed map needs in stride == 2 * out stride (%d, %d)",
-               in->tensor_stride, out->tensor_stride);
-    step = out->tensor_stride;
-    sign = -1;
+               "cs_kernelmap_build: transposed map needs in stride == 2 * out stride (%d, %d)", in->tensor_stride,
+               out->tensor_stride);
+    *step = out->tensor_stride;
+    *sign = -1;
   }
-  ProfScope prof("kmap", s);
-  cs_kernelmap* km = new cs_kernelmap();
-  km->n_out = out->n;
-  km->n_in = in->n;
-  km->kvol = kernel_size == 3 ? 27 : 1;
-  km->transposed = transposed;
+  return CS_OK;
+}
+
+static int ushift_of(int ts) {
+  if (ts <= 0 || (ts & (ts - 1)) != 0) return -1;
+  int sh = 0;
+  while ((1 << sh) < ts) ++sh;
+  return sh;
+}
+
+struct MapPlan {
+  cs_kernelmap* km = nullptr;
+  const cs_coordmap* in = nullptr;
+  const cs_coordmap* out = nullptr;
+  int step = 0, sign = 0;
+  unsigned long long* d_cnt = nullptr;   // device pair counter (zeroed before the streams fork)
+  bool fused = false;                    // built by k_level_maps (keys come out of the builder)
+  bool ordered = false;                  // gets a tiling order (kvol 27, n_out > 0)
+  int64_t base = 0;                      // first element of this map in the batch's sort arrays
+};
+
+// CS_KMAP_TRACE=1: phase stamps of one k_level_maps launch, averaged over its workgroups (synchronises; diagnostics)
+static void level_trace_report(unsigned long long* d_trace, int wgs, int n_jobs, int slots, int nb, int slices,
+                               int64_t n_in, hipStream_t s) {
+  std::vector<unsigned long long> h((size_t)wgs * 8);
+  if (hipStreamSynchronize(s) != hipSuccess) return;
+  if (hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  double ph[8] = {0};
+  int live = 0;
+  unsigned long long t_min = ~0ULL, t_max = 0;
+  for (int w = 0; w < wgs; ++w) {
+    const unsigned long long* t = &h[(size_t)w * 8];
+    if (!t[0]) continue;
+    ++live;
+    for (int i = 1; i < 3 + n_jobs; ++i) ph[i] += (double)(t[i] - t[i - 1]) * 0.01;   // 100 MHz -> us
+    t_min = std::min(t_min, t[0]);
+    t_max = std::max(t_max, t[2 + n_jobs]);
+  }
+  if (!live) return;
+  fprintf(stderr, "[kmap trace] level n_in %lld, %d samples x %d slices, %d slots, %d jobs: box+fill %.1f us, insert %.1f us",
+          (long long)n_in, nb, slices, slots, n_jobs, ph[1] / live, ph[2] / live);
+  for (int j = 0; j < n_jobs; ++j) fprintf(stderr, ", job %d %.1f us", j, ph[3 + j] / live);
+  fprintf(stderr, "; %d workgroups, launch span %.1f us\n", live, (double)(t_max - t_min) * 0.01);
+}
+
+// all fused maps that probe the table of `in`, on stream s: jobs[0..nj) index into plans
+static int launch_level(const cs_coordmap* in, const MapPlan* plans, const int* jobs, int nj, uint32_t* key, int32_t* row,
+                        hipStream_t s) {
+  cs_coordmap* in_m = const_cast<cs_coordmap*>(in);
+  const int nb = in_m->n_batch;
+  LevelArgs a;
+  a.n_jobs = nj;
+  for (int j = 0; j < nj; ++j) {
+    const MapPlan& p = plans[jobs[j]];
+    LevelJob& J = a.job[j];
+    J.out_coords = p.out->d_coords;
+    J.out_seg = p.out->d_seg;
+    J.nbr = p.km->d_nbr;
+    J.key = p.ordered ? key + p.base : nullptr;
+    J.row = p.ordered ? row + p.base : nullptr;
+    J.cnt = p.d_cnt;
+    J.step = p.step;
+    J.sign = p.sign;
+    J.tag = (uint32_t)(jobs[j] % ORDER_MAX_MAPS) << 27;
+  }
+  a.in_coords = in->d_coords;
+  a.in_seg = in_m->d_seg;
+  a.unit = in->tensor_stride;
+  a.ushift = ushift_of(in->tensor_stride);
+  a.gkeys = in->d_keys;
+  a.gvals = in->d_vals;
+  a.gmask = in->capacity - 1;
+  a.trace = nullptr;
+  // workgroups per level: one per CU and more (a slice re-inserts its sample: 512 workgroups build every table twice as
+  // often as 256 for the same probes); CS_KMAP_WGS overrides
+  static const int slice_wgs = getenv("CS_KMAP_WGS") ? std::max(atoi(getenv("CS_KMAP_WGS")), 1) : 256;
+  int slices = slice_wgs / (nb > 0 ? nb : 1);
+  slices = std::min(std::max(slices, 1), 8);
+  // table size from the mean in-sample size (2.5x headroom; a larger sample is probed in the global table)
+  const int64_t need = (in->n / (nb > 0 ? nb : 1)) * 5 / 2;
+  static const bool small_tables = !(getenv("CS_KMAP_SMALL") && getenv("CS_KMAP_SMALL")[0] == '0');
+  const int slots = (small_tables && need <= 2048 / 8 * 5) ? 2048 : (small_tables && need <= 8192 / 8 * 5) ? 8192 : LDS_SLOTS_MAX;
+  static const bool trace_on = getenv("CS_KMAP_TRACE") && getenv("CS_KMAP_TRACE")[0] == '1';
+  const int wgs = slices * nb;
+  if (trace_on) {
+    if (hipMalloc(reinterpret_cast<void**>(&a.trace), (size_t)wgs * 64) != hipSuccess) a.trace = nullptr;
+    if (a.trace) (void)hipMemsetAsync(a.trace, 0, (size_t)wgs * 64, s);
+  }
+  const dim3 grid((unsigned)slices, (unsigned)nb);
+  if (slots == 2048)
+    hipLaunchKernelGGL((k_level_maps<2048, 256>), grid, dim3(256), 0, s, a);
+  else if (slots == 8192)
+    hipLaunchKernelGGL((k_level_maps<8192, 512>), grid, dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_level_maps<LDS_SLOTS_MAX, 1024>), grid, dim3(1024), 0, s, a);
+  CS_LAUNCH_CHECK();
+  if (a.trace) {
+    level_trace_report(a.trace, wgs, nj, slots, nb, slices, in->n, s);
+    (void)hipFree(a.trace);
+  }
+  return CS_OK;
+}
+
+// one map through the GLOBAL table (kvol 1, rows not grouped by sample, CS_KMAP_GLOBAL) -- or, CS_KMAP_FUSED=0, through
+// the round-4 per-map LDS kernels (kept for the A/B against k_level_maps)
+static int launch_single(const MapPlan& p, bool legacy_lds, hipStream_t s) {
+  cs_kernelmap* km = p.km;
   const int64_t total = km->n_out * km->kvol;
-  km->d_nbr = (int32_t*)pool_alloc((total ? total : 1) * sizeof(int32_t));
-  PoolBuf<unsigned long long> cnt(1);
-  if (!km->d_nbr || !cnt.p) {
-    cs_kernelmap_free(km);
-    set_error("cs_kernelmap_build: allocation failed");
-    return CS_ERR_HIP;
-  }
-  hipError_t e = hipSuccess;
-  // LDS path: per-sample hash tables (see k_build_nbr_lds), the flagged samples through the global
-  // table right behind it; otherwise the global table for everything.  No host decision in between:
-  // the pair count travels to a page-locked slot and is read when somebody asks (kernelmap_pairs).
-  bool used_lds = false;
-  PoolBuf<int> fb;
-  const unsigned long long* d_cnt = cnt.p;
-  if (e == hipSuccess && total > 0 && km->kvol == 27 && getenv("CS_KMAP_GLOBAL") == nullptr) {
-    cs_coordmap* in_m = const_cast<cs_coordmap*>(in);
-    cs_coordmap* out_m = const_cast<cs_coordmap*>(out);
-    if (ensure_segments(in_m, s) == CS_OK && ensure_segments(out_m, s) == CS_OK &&
-        in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch) {
-      const int nb = in_m->n_batch;
-      // pair counter and per-sample fallback flags in one block: one memset
-      fb.alloc(2 + nb);
-      if (fb.p) {
-        unsigned long long* const cnt_p = reinterpret_cast<unsigned long long*>(fb.p);
-        int* const fb_p = fb.p + 2;
-        const int ts_in = in->tensor_stride;
-        int ushift = -1;
-        if (ts_in > 0 && (ts_in & (ts_in - 1)) == 0) {
-          ushift = 0;
-          while ((1 << ushift) < ts_in) ++ushift;
-        }
-        // workgroups per map: one per CU.  Every slice of a sample rebuilds the sample's table, so 512 workgroups (two
-        // rounds on 256 CUs with the 144-KB tables) build every table twice as often as 256 do for the same probes:
-        // stress 6 330 -> 6 430 clouds/s (CS_KMAP_WGS=128 / 256 / 512 / 1024: 6 235 / 6 430 / 6 330 / 6 312)
-        static const int slice_wgs = getenv("CS_KMAP_WGS") ? std::max(atoi(getenv("CS_KMAP_WGS")), 1) : 256;
-        int slices = slice_wgs / (nb > 0 ? nb : 1);
-        if (slices < 1) slices = 1;
-        if (slices > 8) slices = 8;
-        e = hipMemsetAsync(fb.p, 0, sizeof(int) * (2 + nb), s);
-        if (e == hipSuccess) {
-          // table size from the mean in-sample size (2.5x headroom; larger samples take the flagged path)
-          const int64_t need = (in->n / (nb > 0 ? nb : 1)) * 5 / 2;
-          static const bool small_tables = !(getenv("CS_KMAP_SMALL") && getenv("CS_KMAP_SMALL")[0] == '0');
-          // submanifold map (same coordinate map on both sides, plain convolution): half of the probes
-          // (maps of >= 200 000 rows: below that the table fill and the scattered mirror writes cost what the probes
-          // save -- stress 7 217 -> 7 317 clouds/s, the 160 000-row maps of the chair batch unchanged either way)
-          // CS_KMAP_SYM=0 / 1: never / whatever the size (tests)
-          const char* env_sym = getenv("CS_KMAP_SYM");
-          const bool sym = in == out && !transposed && sign > 0 &&
-                           (env_sym ? env_sym[0] == '1' : km->n_out >= 200000);
-          if (sym) e = hipMemsetAsync(km->d_nbr, 0xff, (size_t)total * sizeof(int32_t), s);
+  if (total == 0) return CS_OK;
+  cs_coordmap* in_m = const_cast<cs_coordmap*>(p.in);
+  cs_coordmap* out_m = const_cast<cs_coordmap*>(p.out);
+  if (legacy_lds && km->kvol == 27 && in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch) {
+    const int nb = in_m->n_batch;
+    PoolBuf<int> fb(nb);
+    CS_REQUIRE(fb.p, CS_ERR_HIP, "cs_kernelmap_build: allocation failed");
+    CS_HIP_CHECK(hipMemsetAsync(fb.p, 0, sizeof(int) * nb, s));
+    static const int slice_wgs = getenv("CS_KMAP_WGS") ? std::max(atoi(getenv("CS_KMAP_WGS")), 1) : 256;
+    int slices = std::min(std::max(slice_wgs / (nb > 0 ? nb : 1), 1), 8);
+    const int64_t need = (p.in->n / (nb > 0 ? nb : 1)) * 5 / 2;
+    const char* env_sym = getenv("CS_KMAP_SYM");
+    const bool sym = p.in == p.out && !km->transposed && (env_sym ? env_sym[0] == '1' : km->n_out >= 200000);
+    if (sym) CS_HIP_CHECK(hipMemsetAsync(km->d_nbr, 0xff, (size_t)total * sizeof(int32_t), s));
+    const int ushift = ushift_of(p.in->tensor_stride);
 #define CS_NBR_LDS(SLOTS_, NT_)                                                                                          \
   do {                                                                                                                    \
     if (sym)                                                                                                              \
       hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, true>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,      \
-                         in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg, in->tensor_stride, ushift, step, sign,   \
-                         km->d_nbr, cnt_p, fb_p);                                                                         \
+                         p.in->d_coords, in_m->d_seg, p.out->d_coords, out_m->d_seg, p.in->tensor_stride, ushift, p.step, \
+                         p.sign, km->d_nbr, p.d_cnt, fb.p);                                                               \
     else                                                                                                                  \
       hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, false>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,     \
-                         in->d_coords, in_m->d_seg, out->d_coords, out_m->d_seg, in->tensor_stride, ushift, step, sign,   \
-                         km->d_nbr, cnt_p, fb_p);                                                                         \
+                         p.in->d_coords, in_m->d_seg, p.out->d_coords, out_m->d_seg, p.in->tensor_stride, ushift, p.step, \
+                         p.sign, km->d_nbr, p.d_cnt, fb.p);                                                               \
   } while (0)
-          if (e != hipSuccess) {
-          } else if (small_tables && need <= 2048 / 8 * 5)
-            CS_NBR_LDS(2048, 256);
-          else if (small_tables && need <= 8192 / 8 * 5)
-            CS_NBR_LDS(8192, 512);
-          else
-            CS_NBR_LDS(LDS_SLOTS_MAX, 1024);
+    if (need <= 2048 / 8 * 5)
+      CS_NBR_LDS(2048, 256);
+    else if (need <= 8192 / 8 * 5)
+      CS_NBR_LDS(8192, 512);
+    else
+      CS_NBR_LDS(LDS_SLOTS_MAX, 1024);
 #undef CS_NBR_LDS
-          hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, out->d_coords,
-                             out_m->d_seg, step, sign, in->d_keys, in->d_vals, in->capacity - 1,
-                             km->d_nbr, cnt_p, fb_p);
-          e = hipGetLastError();
-        }
-        if (e == hipSuccess) {
-          used_lds = true;
-          d_cnt = cnt_p;
-        }
-      }
-    }
-  }
-  if (e == hipSuccess && total > 0 && !used_lds) {
-    e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s);   // (the LDS path keeps its counter in `fb`)
-    hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
-                       out->d_coords, km->n_out, km->kvol, step, sign, in->d_keys, in->d_vals,
-                       in->capacity - 1, km->d_nbr, cnt.p, (const int*)nullptr);
-    e = hipGetLastError();
-  }
-  unsigned long long* cnt_host_dev = nullptr;
-  if (e == hipSuccess) {
-    if (total == 0) {
-      km->num_pairs = 0;
-    } else {
-      km->h_cnt = count_slot_acquire(&km->cnt_slot);
-      if (!km->h_cnt || hipEventCreateWithFlags(&km->cnt_ready, hipEventDisableTiming) != hipSuccess) {
-        e = hipErrorOutOfMemory;
-      } else if (km->kvol == 27) {
-        // the row-key kernel (below, or order_many's) writes the count into the page-locked slot itself (no copy launch)
-        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&cnt_host_dev), km->h_cnt, 0) != hipSuccess)
-          cnt_host_dev = nullptr;
-      }
-      if (e == hipSuccess && !cnt_host_dev) {
-        e = hipMemcpyAsync(km->h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipEventRecord(km->cnt_ready, s);
-      }
-    }
-  }
-  if (e != hipSuccess) {
-    cs_kernelmap_free(km);
-    set_error("cs_kernelmap_build: %s", hipGetErrorString(e));
-    return CS_ERR_HIP;
-  }
-  if (defer_order && km->kvol == 27 && km->n_out > 0 && cnt_host_dev) {
-    *d_cnt_out = d_cnt;
-    *km_out = km;
+    hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, p.out->d_coords, out_m->d_seg, p.step,
+                       p.sign, p.in->d_keys, p.in->d_vals, p.in->capacity - 1, km->d_nbr, p.d_cnt, fb.p);
+    CS_LAUNCH_CHECK();
     return CS_OK;
   }
-  // tiling order for the convolution kernels: rows sorted by the Gray rank of their presence mask
-  if (km->kvol == 27 && km->n_out > 0) {
+  hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, p.out->d_coords, km->n_out, km->kvol,
+                     p.step, p.sign, p.in->d_keys, p.in->d_vals, p.in->capacity - 1, km->d_nbr, p.d_cnt, (const int*)nullptr);
+  CS_LAUNCH_CHECK();
+  return CS_OK;
+}
+
+// Tiling order of the maps plans[idx[0..m)] (m <= ORDER_MAX_MAPS, all `ordered`) on stream s, which is behind every stream
+// that built them: keys of the maps the level kernel did not build, ONE radix sort, one finish launch (row lists, group
+// masks, pair counts to the host slots).
+static int order_many(const MapPlan* plans, const int* idx, int m, uint32_t* key, int32_t* row, uint32_t* key_sorted,
+                      int32_t* row_sorted, int64_t first, int64_t total, hipStream_t s) {
+  if (m == 0) return CS_OK;
+  OrderTab tab;
+  tab.n = m;
+  uint64_t kblk = 0, tblk = 0;
+  bool any_keys = false;
+  for (int j = 0; j < m; ++j) {
+    const MapPlan& p = plans[idx[j]];
+    cs_kernelmap* km = p.km;
+    OrderMap& o = tab.m[j];
     const int64_t n = km->n_out;
+    o.n_out = n;
+    o.base = p.base - first;
+    o.n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
+    o.nbr = km->d_nbr;
     km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
-    PoolBuf<uint32_t> key(n), key_sorted(n);
-    PoolBuf<int32_t> row(n);
-    const bool small = n <= SORT_SMALL_MAX;
-    size_t tmp_bytes = 0;
-    hipError_t e2 = small ? hipSuccess
-                          : hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p,
-                                                               km->d_rowlist, (int)n, 0, 27, s);
-    PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
-    if (!km->d_rowlist || !key.p || !key_sorted.p || !row.p || !tmp.p) {
-      cs_kernelmap_free(km);
-      set_error("cs_kernelmap_build: row list allocation failed");
-      return CS_ERR_HIP;
-    }
-    hipLaunchKernelGGL(k_row_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, km->d_nbr, n, km->kvol, key.p,
-                       row.p, d_cnt, cnt_host_dev);
-    if (cnt_host_dev && hipEventRecord(km->cnt_ready, s) != hipSuccess) e2 = hipErrorUnknown;
-    if (small) {
-      int npow2 = 2;
-      while (npow2 < n) npow2 <<= 1;
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_small),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         SORT_SMALL_MAX * (int)sizeof(unsigned long long));
-      if (e2 == hipSuccess) e2 = attr;   // (keeps an earlier error, e.g. of the cnt_ready record)
-      if (e2 == hipSuccess)
-        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), (size_t)npow2 * sizeof(unsigned long long), s, key.p, (int)n,
-                           npow2, key_sorted.p, km->d_rowlist);
-    } else if (e2 == hipSuccess) {
-      e2 = hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, km->d_rowlist, (int)n, 0,
-                                              27, s);
-    }
-    const int64_t n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
-    km->d_nbr_sorted = (int32_t*)pool_alloc((size_t)n * km->kvol * sizeof(int32_t));
-    km->d_gmask = (uint32_t*)pool_alloc((size_t)n_groups * sizeof(uint32_t));
-    if (!km->d_nbr_sorted || !km->d_gmask) {
-      cs_kernelmap_free(km);
-      set_error("cs_kernelmap_build: sorted table allocation failed");
-      return CS_ERR_HIP;
-    }
-    hipLaunchKernelGGL(k_sorted_tables, dim3((unsigned)ceil_div(n * km->kvol, 256)), dim3(256), 0, s, km->d_nbr,
-                       km->d_rowlist, key_sorted.p, n, km->kvol, km->d_nbr_sorted, km->d_gmask, n_groups, (int32_t)km->n_in);
-    if (e2 == hipSuccess) e2 = hipGetLastError();
-    // no synchronisation: the scratch returns to this thread's stream-ordered cache
-    if (e2 != hipSuccess) {
-      cs_kernelmap_free(km);
-      set_error("cs_kernelmap_build: row grouping failed: %s", hipGetErrorString(e2));
-      return CS_ERR_HIP;
-    }
+    km->d_gmask = (uint32_t*)pool_alloc((size_t)o.n_groups * sizeof(uint32_t));
+    CS_REQUIRE(km->d_rowlist && km->d_gmask, CS_ERR_HIP, "cs_kernelmap_build_many: tiling order allocation failed");
+    o.rowlist = km->d_rowlist;
+    o.gmask = km->d_gmask;
+    o.d_cnt = p.d_cnt;
+    o.host_cnt = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&o.host_cnt), km->h_cnt, 0) != hipSuccess) o.host_cnt = nullptr;
+    CS_REQUIRE(o.host_cnt, CS_ERR_HIP, "cs_kernelmap_build_many: no device view of the pair-count slot");
+    o.tag = (uint32_t)(idx[j] % ORDER_MAX_MAPS) << 27;
+    o.need_keys = p.fused ? 0 : 1;
+    any_keys = any_keys || !p.fused;
+    o.kblk0 = (uint32_t)kblk;
+    o.tblk0 = (uint32_t)tblk;
+    kblk += (uint64_t)ceil_div(n, 256);
+    tblk += (uint64_t)std::max<int64_t>(ceil_div(n, 256), 1);
   }
-  *km_out = km;
+  CS_REQUIRE(total < (1LL << 31) && kblk < (1ULL << 31), CS_ERR_UNSUPPORTED, "cs_kernelmap_build_many: batch too large");
+  int map_bits = 0;
+  while ((1 << map_bits) < ORDER_MAX_MAPS) ++map_bits;
+  size_t tmp_bytes = 0;
+  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key + first, key_sorted + first, row + first,
+                                                  row_sorted + first, (int)total, 0, 27 + map_bits, s));
+  PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+  CS_REQUIRE(tmp.p, CS_ERR_HIP, "cs_kernelmap_build_many: row order scratch allocation failed");
+  if (any_keys) {
+    hipLaunchKernelGGL(k_row_keys_all, dim3((unsigned)kblk), dim3(256), 0, s, tab, key + first, row + first);
+    CS_LAUNCH_CHECK();
+  }
+  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key + first, key_sorted + first, row + first,
+                                                  row_sorted + first, (int)total, 0, 27 + map_bits, s));
+  hipLaunchKernelGGL(k_order_finish, dim3((unsigned)tblk), dim3(256), 0, s, tab, key_sorted + first, row_sorted + first);
+  CS_LAUNCH_CHECK();
+  for (int j = 0; j < m; ++j) CS_HIP_CHECK(hipEventRecord(plans[idx[j]].km->cnt_ready, s));
   return CS_OK;
 }
 
 extern "C" {
 
-int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size,
-                       int transposed, void* stream, cs_kernelmap** km_out) {
-  pool_use_stream((hipStream_t)stream);
-  return kernelmap_build_on(in, out, kernel_size, transposed, (hipStream_t)stream, km_out);
-}
-
-// Tiling order of the maps kms[idx[0..m)] (all kvol 27, n_out > 0, built with defer_order) on stream s, which is
-// behind every stream that built them: one key launch, one radix sort, one table launch.
-static int order_many(cs_kernelmap* const* kms, const unsigned long long* const* d_cnts, const int* idx, int m,
-                      hipStream_t s) {
-  if (m == 0) return CS_OK;
-  OrderTab tab;
-  tab.n = m;
-  int64_t total = 0;
-  uint64_t kblk = 0, tblk = 0;
-  for (int j = 0; j < m; ++j) {
-    cs_kernelmap* km = kms[idx[j]];
-    OrderMap& o = tab.m[j];
-    const int64_t n = km->n_out;
-    o.n_out = n;
-    o.base = total;
-    o.n_groups = ceil_div(ceil_div(n, 32), 8) * 8;
-    o.absent = (int32_t)km->n_in;
-    o.nbr = km->d_nbr;
-    km->d_rowlist = (int32_t*)pool_alloc(n * sizeof(int32_t));
-    km->d_nbr_sorted = (int32_t*)pool_alloc((size_t)n * 27 * sizeof(int32_t));
-    km->d_gmask = (uint32_t*)pool_alloc((size_t)o.n_groups * sizeof(uint32_t));
-    CS_REQUIRE(km->d_rowlist && km->d_nbr_sorted && km->d_gmask, CS_ERR_HIP, "cs_kernelmap_build_many: sorted table allocation failed");
-    o.rowlist = km->d_rowlist;
-    o.nbr_sorted = km->d_nbr_sorted;
-    o.gmask = km->d_gmask;
-    o.d_cnt = d_cnts[idx[j]];
-    o.host_cnt = nullptr;
-    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&o.host_cnt), km->h_cnt, 0) != hipSuccess) o.host_cnt = nullptr;
-    CS_REQUIRE(o.host_cnt, CS_ERR_HIP, "cs_kernelmap_build_many: no device view of the pair-count slot");
-    o.kblk0 = (uint32_t)kblk;
-    o.tblk0 = (uint32_t)tblk;
-    kblk += (uint64_t)ceil_div(n, 256);
-    tblk += (uint64_t)ceil_div(n * 27, 256);
-    total += n;
-  }
-  CS_REQUIRE(total < (1LL << 31) && tblk < (1ULL << 31), CS_ERR_UNSUPPORTED, "cs_kernelmap_build_many: batch too large");
-  int map_bits = 0;
-  while ((1 << map_bits) < m) ++map_bits;
-  PoolBuf<uint32_t> key(total), key_sorted(total);
-  PoolBuf<int32_t> row(total), row_sorted(total);
-  size_t tmp_bytes = 0;
-  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key_sorted.p, row.p, row_sorted.p, (int)total, 0,
-                                                  27 + map_bits, s));
-  PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
-  CS_REQUIRE(key.p && key_sorted.p && row.p && row_sorted.p && tmp.p, CS_ERR_HIP,
-             "cs_kernelmap_build_many: row order scratch allocation failed");
-  hipLaunchKernelGGL(k_row_keys_all, dim3((unsigned)kblk), dim3(256), 0, s, tab, key.p, row.p);
-  CS_LAUNCH_CHECK();
-  for (int j = 0; j < m; ++j) CS_HIP_CHECK(hipEventRecord(kms[idx[j]]->cnt_ready, s));
-  CS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key_sorted.p, row.p, row_sorted.p, (int)total, 0,
-                                                  27 + map_bits, s));
-  hipLaunchKernelGGL(k_sorted_tables_all, dim3((unsigned)tblk), dim3(256), 0, s, tab, key_sorted.p, row_sorted.p);
-  CS_LAUNCH_CHECK();
-  return CS_OK;
-}
-
-// The kernel maps of a batch are independent chains of ~10-20 small dependent launches each (table, row keys, sort,
-// tiling-order tables): enqueued one behind the other they are bound by launch latency, not by the GPU.  Here map i
-// goes to stream i % N (the caller's, and N - 1 of the thread's side streams): every side stream starts behind the caller's
-// stream and the caller's stream continues behind all of them; scratch freed meanwhile is handed back to the pool
-// only after that join.  CS_KMAP_STREAMS=1: everything on the caller's stream.
+// The kernel maps of a batch.  Maps are grouped by the coordinate level they PROBE (their `in` map): one k_level_maps launch
+// per level serves every map of the group from one LDS table per sample, and the levels run on up to four streams (the
+// caller's and the thread's side streams: every side stream starts behind the caller's stream and the caller's stream
+// continues behind all of them; scratch freed meanwhile is handed back to the pool only after that join).  Then ONE radix
+// sort gives every map its tiling order.  CS_KMAP_STREAMS=1: everything on the caller's stream; CS_KMAP_FUSED=0: the
+// round-4 per-map kernels; CS_KMAP_GLOBAL=1: the global-table kernel for everything.
 int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordmap* const* out, const int* kernel_size,
                             const int* transposed, void* stream, cs_kernelmap** km_out) {
   CS_REQUIRE(n >= 0 && (n == 0 || (in && out && kernel_size && transposed && km_out)), CS_ERR_INVALID,
@@ -1194,6 +1274,27 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
   for (int i = 0; i < n; ++i) km_out[i] = nullptr;
+  if (n == 0) return CS_OK;
+  std::vector<MapPlan> plans(n);
+  for (int i = 0; i < n; ++i) {
+    const int rc = map_geometry(in[i], out[i], kernel_size[i], transposed[i], &plans[i].step, &plans[i].sign);
+    if (rc != CS_OK) return rc;
+    plans[i].in = in[i];
+    plans[i].out = out[i];
+  }
+  const bool global_only = getenv("CS_KMAP_GLOBAL") != nullptr;
+  static const bool fused_on = !(getenv("CS_KMAP_FUSED") && getenv("CS_KMAP_FUSED")[0] == '0');
+  // per-sample segments of the coordinate maps (lazily, cached on the map): on the caller's stream before the streams fork
+  if (!global_only) {
+    std::vector<cs_coordmap*> need;
+    for (int i = 0; i < n; ++i)
+      if (kernel_size[i] == 3) {
+        need.push_back(const_cast<cs_coordmap*>(in[i]));
+        need.push_back(const_cast<cs_coordmap*>(out[i]));
+      }
+    const int rc_seg = ensure_segments_many(need.data(), (int)need.size(), s);
+    if (rc_seg != CS_OK) return rc_seg;
+  }
   static const int n_streams = [] {
     const char* e = getenv("CS_KMAP_STREAMS");
     int v = e ? atoi(e) : 4;   // 2 / 3 / 4 / 5 streams: stress 6016 / 6201 / 6235 / 5608 clouds/s (the runtime maps streams to 4 queues)
@@ -1203,81 +1304,164 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
   for (int k = 1; k < n_streams; ++k) st[k] = side_stream(k - 1);
   int ns = 1;
   while (ns < n_streams && st[ns]) ++ns;
-  if (ns == 1 || n < 2) {
+
+  int rc = CS_OK;
+  hipError_t je = hipSuccess;
+  auto fail = [&](int code) {
     for (int i = 0; i < n; ++i) {
-      const int rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], s, &km_out[i]);
-      if (rc != CS_OK) {
-        for (int j = 0; j < i; ++j) { cs_kernelmap_free(km_out[j]); km_out[j] = nullptr; }
-        return rc;
-      }
+      if (plans[i].km) cs_kernelmap_free(plans[i].km);
+      km_out[i] = nullptr;
     }
-    return CS_OK;
+    pool_defer_end();
+    return code;
+  };
+  pool_defer_begin();
+  // ---- map objects, counters, the batch's sort arrays ----
+  PoolBuf<unsigned long long> cnts(n);
+  if (!cnts.p) {
+    set_error("cs_kernelmap_build_many: allocation failed");
+    return fail(CS_ERR_HIP);
   }
-  // per-sample segments of the coordinate maps are made lazily by the first map that needs them: make them on the
-  // caller's stream before the streams fork
-  {
-    std::vector<cs_coordmap*> need;
-    for (int i = 0; i < n; ++i) {
-      CS_REQUIRE(in[i] && out[i], CS_ERR_INVALID, "cs_kernelmap_build_many: NULL coordinate map");
-      if (kernel_size[i] == 3 && getenv("CS_KMAP_GLOBAL") == nullptr) {
-        need.push_back(const_cast<cs_coordmap*>(in[i]));
-        need.push_back(const_cast<cs_coordmap*>(out[i]));
-      }
+  int64_t total_rows = 0;
+  for (int i = 0; i < n; ++i) {
+    MapPlan& p = plans[i];
+    cs_kernelmap* km = new cs_kernelmap();
+    p.km = km;
+    km->n_out = out[i]->n;
+    km->n_in = in[i]->n;
+    km->kvol = kernel_size[i] == 3 ? 27 : 1;
+    km->transposed = transposed[i];
+    const int64_t total = km->n_out * km->kvol;
+    km->d_nbr = (int32_t*)pool_alloc((total ? total : 1) * sizeof(int32_t));
+    p.d_cnt = cnts.p + i;
+    if (!km->d_nbr) {
+      set_error("cs_kernelmap_build_many: allocation failed");
+      return fail(CS_ERR_HIP);
     }
-    const int rc_seg = ensure_segments_many(need.data(), (int)need.size(), s);
-    if (rc_seg != CS_OK) return rc_seg;
+    if (total == 0) {
+      km->num_pairs = 0;
+      continue;
+    }
+    km->h_cnt = count_slot_acquire(&km->cnt_slot);
+    if (!km->h_cnt || hipEventCreateWithFlags(&km->cnt_ready, hipEventDisableTiming) != hipSuccess) {
+      set_error("cs_kernelmap_build_many: pair-count slot allocation failed");
+      return fail(CS_ERR_HIP);
+    }
+    cs_coordmap* in_m = const_cast<cs_coordmap*>(in[i]);
+    cs_coordmap* out_m = const_cast<cs_coordmap*>(out[i]);
+    p.ordered = km->kvol == 27;
+    p.fused = fused_on && !global_only && km->kvol == 27 && in_m->seg_state == 1 && out_m->seg_state == 1 &&
+              in_m->n_batch == out_m->n_batch;
+    if (p.ordered) {
+      p.base = total_rows;
+      total_rows += km->n_out;
+    }
   }
+  if (total_rows >= (1LL << 31)) {
+    set_error("cs_kernelmap_build_many: batch too large");
+    return fail(CS_ERR_UNSUPPORTED);
+  }
+  PoolBuf<uint32_t> key(total_rows), key_sorted(total_rows);
+  PoolBuf<int32_t> row(total_rows), row_sorted(total_rows);
+  if (!key.p || !key_sorted.p || !row.p || !row_sorted.p) {
+    set_error("cs_kernelmap_build_many: row order scratch allocation failed");
+    return fail(CS_ERR_HIP);
+  }
+  if (hipMemsetAsync(cnts.p, 0, sizeof(unsigned long long) * n, s) != hipSuccess) {
+    set_error("cs_kernelmap_build_many: memset failed");
+    return fail(CS_ERR_HIP);
+  }
+  // ---- fork ----
   struct Ev {
     hipEvent_t e = nullptr;
     ~Ev() { if (e) (void)hipEventDestroy(e); }
   } fork, join[5];
-  CS_HIP_CHECK(hipEventCreateWithFlags(&fork.e, hipEventDisableTiming));
-  CS_HIP_CHECK(hipEventRecord(fork.e, s));
-  for (int k = 1; k < ns; ++k) {
-    CS_HIP_CHECK(hipEventCreateWithFlags(&join[k].e, hipEventDisableTiming));
-    CS_HIP_CHECK(hipStreamWaitEvent(st[k], fork.e, 0));
-  }
-  // CS_KMAP_ORDER_MANY=0: every map orders its own rows on its own stream (the round-3 path)
-  static const bool order_all = !(getenv("CS_KMAP_ORDER_MANY") && getenv("CS_KMAP_ORDER_MANY")[0] == '0');
-  const bool defer = order_all && n <= ORDER_MAX_MAPS;
-  std::vector<const unsigned long long*> d_cnts(n, nullptr);
-  pool_defer_begin();
-  int rc = CS_OK;
-  for (int i = 0; i < n && rc == CS_OK; ++i)
-    rc = kernelmap_build_on(in[i], out[i], kernel_size[i], transposed[i], st[i % ns], &km_out[i], defer, &d_cnts[i]);
-  // join (also on the error path: the side streams may hold work that reads scratch of this call)
-  hipError_t je = hipSuccess;
-  for (int k = 1; k < ns; ++k) {
-    hipError_t e1 = hipEventRecord(join[k].e, st[k]);
-    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, join[k].e, 0);
-    if (e1 != hipSuccess) {
-      (void)hipStreamSynchronize(st[k]);
-      je = e1;
+  if (ns > 1) {
+    hipError_t e = hipEventCreateWithFlags(&fork.e, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(fork.e, s);
+    for (int k = 1; k < ns && e == hipSuccess; ++k) {
+      e = hipEventCreateWithFlags(&join[k].e, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st[k], fork.e, 0);
+    }
+    if (e != hipSuccess) {
+      set_error("cs_kernelmap_build_many: %s", hipGetErrorString(e));
+      return fail(CS_ERR_HIP);
     }
   }
-  // the tiling order of all deferred maps in one pass on the caller's stream, behind the join and BEFORE the deferred
-  // scratch (the maps' device counters) goes back to the pool
-  if (rc == CS_OK && je == hipSuccess && defer) {
-    std::vector<int> idx;
-    for (int i = 0; i < n; ++i)
-      if (km_out[i] && d_cnts[i]) idx.push_back(i);
+  // ---- builders: one launch per probed level (fused maps), one per remaining map ----
+  {
     ProfScope prof("kmap", s);
-    rc = order_many(km_out, d_cnts.data(), idx.data(), (int)idx.size(), s);
+    int lane = 0;
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n && rc == CS_OK; ++i) {
+      if (done[i] || !plans[i].fused) continue;
+      int jobs[LEVEL_MAX_JOBS], nj = 0;
+      for (int j = i; j < n && nj < LEVEL_MAX_JOBS; ++j)
+        if (!done[j] && plans[j].fused && in[j] == in[i] && (j / ORDER_MAX_MAPS) == (i / ORDER_MAX_MAPS)) {
+          jobs[nj++] = j;
+          done[j] = 1;
+        }
+      rc = launch_level(in[i], plans.data(), jobs, nj, key.p, row.p, st[lane++ % ns]);
+    }
+    for (int i = 0; i < n && rc == CS_OK; ++i) {
+      if (done[i]) continue;
+      rc = launch_single(plans[i], !fused_on && !global_only, st[lane++ % ns]);
+    }
+    // join (also on the error path: the side streams may hold work that reads scratch of this call)
+    for (int k = 1; k < ns; ++k) {
+      hipError_t e1 = hipEventRecord(join[k].e, st[k]);
+      if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, join[k].e, 0);
+      if (e1 != hipSuccess) {
+        (void)hipStreamSynchronize(st[k]);
+        je = e1;
+      }
+    }
+  }
+  // ---- tiling order of all ordered maps (ONE sort per ORDER_MAX_MAPS maps) on the caller's stream, behind the join ----
+  if (rc == CS_OK && je == hipSuccess) {
+    ProfScope prof("kmap", s);
+    for (int c0 = 0; c0 < n && rc == CS_OK; c0 += ORDER_MAX_MAPS) {
+      int idx[ORDER_MAX_MAPS], m = 0;
+      int64_t first = -1, rows = 0;
+      for (int i = c0; i < std::min(n, c0 + ORDER_MAX_MAPS); ++i)
+        if (plans[i].ordered) {
+          if (first < 0) first = plans[i].base;
+          rows += plans[i].km->n_out;
+          idx[m++] = i;
+        }
+      if (m) rc = order_many(plans.data(), idx, m, key.p, row.p, key_sorted.p, row_sorted.p, first, rows, s);
+    }
+    // maps without a tiling order (1x1 "maps"): the count goes to the host slot by a copy
+    for (int i = 0; i < n && rc == CS_OK; ++i) {
+      cs_kernelmap* km = plans[i].km;
+      if (plans[i].ordered || km->num_pairs == 0) continue;
+      hipError_t e = hipMemcpyAsync(km->h_cnt, plans[i].d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipEventRecord(km->cnt_ready, s);
+      if (e != hipSuccess) {
+        set_error("cs_kernelmap_build_many: %s", hipGetErrorString(e));
+        rc = CS_ERR_HIP;
+      }
+    }
   }
   if (rc != CS_OK || je != hipSuccess) {
-    for (int i = 0; i < n; ++i) {
-      if (km_out[i]) cs_kernelmap_free(km_out[i]);
-      km_out[i] = nullptr;
-    }
-    pool_defer_end();
     if (rc == CS_OK) {
       set_error("cs_kernelmap_build_many: joining the streams failed: %s", hipGetErrorString(je));
       rc = CS_ERR_HIP;
     }
-    return rc;
+    return fail(rc);
   }
+  for (int i = 0; i < n; ++i) km_out[i] = plans[i].km;
   pool_defer_end();
   return CS_OK;
+}
+
+int cs_kernelmap_build(const cs_coordmap* in, const cs_coordmap* out, int kernel_size, int transposed, void* stream,
+                       cs_kernelmap** km_out) {
+  CS_REQUIRE(km_out, CS_ERR_INVALID, "cs_kernelmap_build: NULL argument");
+  *km_out = nullptr;
+  const cs_coordmap* ins[1] = {in};
+  const cs_coordmap* outs[1] = {out};
+  return cs_kernelmap_build_many(1, ins, outs, &kernel_size, &transposed, stream, km_out);
 }
 
 int64_t cs_kernelmap_num_pairs(const cs_kernelmap* km) { return cs::kernelmap_pairs(km); }
@@ -1314,7 +1498,6 @@ void cs_kernelmap_free(cs_kernelmap* km) {
   if (!km) return;
   pool_free(km->d_nbr);
   pool_free(km->d_rowlist);
-  pool_free(km->d_nbr_sorted);
   pool_free(km->d_gmask);
   if (km->cnt_ready) {
     (void)hipEventSynchronize(km->cnt_ready);  // the slot must not be recycled under a pending copy
