@@ -32,6 +32,7 @@ def _declare(lib):
         "cs_device_count": (c_int, []),
         "cs_coordmap_create": (c_int, [vp, c_int64, c_int, vp, POINTER(vp)]),
         "cs_coordmap_stride": (c_int, [vp, c_int, vp, POINTER(vp)]),
+        "cs_coordmap_pyramid": (c_int, [vp, c_int64, c_int, c_int, c_int, vp, POINTER(vp)]),
         "cs_coordmap_size": (c_int64, [vp]),
         "cs_coordmap_tensor_stride": (c_int, [vp]),
         "cs_coordmap_coords": (vp, [vp]),

@@ -54,6 +54,20 @@ class CoordMap:
                                              stream_ptr(), ctypes.byref(out)))
         return cls(out.value, coords.device)
 
+    @classmethod
+    def pyramid(cls, coords, n_levels=4, n_batch=0, tensor_stride=1):
+        """The maps of tensor strides ts, 2 ts, 4 ts, ... in ONE library call (cs_coordmap_pyramid): the same maps as
+        create() followed by chained stride(2) calls, with one host wait instead of one per level.  n_batch > 0 announces
+        sparse_collate's order (rows grouped by sample, batch indices < n_batch)."""
+        _lib.require_gpu()
+        coords = _dev(coords, torch.int32, "coordinates").contiguous()
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("coordinates must be int32 [N, 4] (batch, x, y, z)")
+        outs = (c_void_p * n_levels)()
+        check(_lib.load().cs_coordmap_pyramid(ptr(coords), coords.shape[0], tensor_stride, n_levels, int(n_batch or 0),
+                                              stream_ptr(), outs))
+        return [cls(h, coords.device) for h in outs]
+
     def stride(self, s=2):
         out = c_void_p()
         check(_lib.load().cs_coordmap_stride(self._h, s, stream_ptr(), ctypes.byref(out)))

@@ -119,6 +119,135 @@ __global__ void k_emit_strided(const int32_t* __restrict__ coords, int64_t n, in
   vals[slot] = o;  // exactly one row per key reaches here
 }
 
+// ---- all coordinate levels of a batch in one pass (round 5: cs_coordmap_pyramid) -------------------------------------------
+// The strided maps of a ResUNet batch (tensor strides 2, 4, 8) used to be a chain c1 -> c2 -> c4 -> c8 of
+// insert / flag / scan / host round trip / emit, one link per level and one host wait per link, plus two more waits for the
+// per-sample segments: six GPU-idle round trips and ~25 launches per forward.  The unique cells of stride 2^l in
+// first-occurrence order are the same whether they are taken from the level below or from the stride-1 rows (the first
+// stride-1 row of a coarse cell is also the first row of its finer cell, and every level keeps first-occurrence order), so
+// all levels come from the stride-1 coordinates at once: one insert kernel (a thread reads its row once and has its four
+// atomics in flight together), one flag kernel, ONE scan (the three flags packed as 21-bit fields of a 64-bit word), one
+// emit kernel, the segment tables of all levels, and ONE host wait for the sizes.
+constexpr int PYR_MAX_LEVELS = 4;
+constexpr int PYR_FIELD = 21;                       // rows < 2^21: three counters in one 64-bit scan element
+struct PyrLevel {
+  uint64_t* keys;
+  int32_t* vals;
+  uint64_t mask;
+  int32_t* coords;                                  // out (level >= 1)
+  int32_t* seg;                                     // [n_batch + 1] or nullptr
+  int cell;
+};
+struct PyrArgs {
+  int n_levels;
+  PyrLevel lv[PYR_MAX_LEVELS];
+  int n_batch;
+  int* status;                                      // [0] out of range, [1] duplicates, [2 + 2 l] not grouped, [3 + 2 l] unused
+  int32_t* counts;                                  // rows of level l (l >= 1)
+};
+
+__device__ __forceinline__ uint64_t pyr_key(int b, int x, int y, int z, int cell) {
+  return pack_key(b, floor_to_cell(x, cell), floor_to_cell(y, cell), floor_to_cell(z, cell));
+}
+
+__global__ __launch_bounds__(256) void k_pyr_insert(const int32_t* __restrict__ coords, int64_t n, const PyrArgs a) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[i];
+  // (the floor cells of an in-range coordinate are in range: |floor(x)| <= 32767 < 32768 needs x > -32768, checked here)
+  if (!coord_in_range(c.x, c.y, c.z, c.w)) {
+    atomicOr(&a.status[0], 1);
+    return;
+  }
+  uint64_t key[PYR_MAX_LEVELS], slot[PYR_MAX_LEVELS];
+  unsigned long long old[PYR_MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < PYR_MAX_LEVELS; ++l)
+    if (l < a.n_levels) {
+      const int cell = a.lv[l].cell;
+      // (a floor cell can fall on -32768 when the coordinate itself is in range: refused like cs_coordmap_stride does)
+      if (l > 0 && !coord_in_range(c.x, floor_to_cell(c.y, cell), floor_to_cell(c.z, cell), floor_to_cell(c.w, cell)))
+        atomicOr(&a.status[0], 1);
+      key[l] = pyr_key(c.x, c.y, c.z, c.w, cell);
+      slot[l] = hash64(key[l]) & a.lv[l].mask;
+      old[l] = atomicCAS((unsigned long long*)&a.lv[l].keys[slot[l]], (unsigned long long)kEmptyKey, (unsigned long long)key[l]);
+    }
+#pragma unroll
+  for (int l = 0; l < PYR_MAX_LEVELS; ++l)
+    if (l < a.n_levels) {
+      while (old[l] != kEmptyKey && old[l] != key[l]) {
+        slot[l] = (slot[l] + 1) & a.lv[l].mask;
+        old[l] = atomicCAS((unsigned long long*)&a.lv[l].keys[slot[l]], (unsigned long long)kEmptyKey, (unsigned long long)key[l]);
+      }
+      if (l == 0 && old[l] == key[l]) atomicAdd(&a.status[1], 1);   // level 0 keeps every row: a second one is a duplicate
+      atomicMin(&a.lv[l].vals[slot[l]], (int32_t)i);
+    }
+}
+
+// packed flags: bit field l - 1 = 1 iff row i is the first (minimum) row of its level-l cell
+__global__ __launch_bounds__(256) void k_pyr_flag(const int32_t* __restrict__ coords, int64_t n, const PyrArgs a,
+                                                  unsigned long long* __restrict__ flag) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[i];
+  unsigned long long f = 0;
+#pragma unroll
+  for (int l = 1; l < PYR_MAX_LEVELS; ++l)
+    if (l < a.n_levels) {
+      const int32_t v = hash_lookup(a.lv[l].keys, a.lv[l].vals, a.lv[l].mask, pyr_key(c.x, c.y, c.z, c.w, a.lv[l].cell));
+      if (v == (int32_t)i) f |= 1ULL << (PYR_FIELD * (l - 1));
+    }
+  flag[i] = f;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_emit(const int32_t* __restrict__ coords, int64_t n, const PyrArgs a,
+                                                  const unsigned long long* __restrict__ flag,
+                                                  const unsigned long long* __restrict__ pos) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long f = flag[i], p = pos[i];
+  if (i == n - 1) {
+#pragma unroll
+    for (int l = 1; l < PYR_MAX_LEVELS; ++l)
+      if (l < a.n_levels)
+        a.counts[l] = (int32_t)(((p + f) >> (PYR_FIELD * (l - 1))) & ((1ULL << PYR_FIELD) - 1));
+  }
+  if (!f) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[i];
+#pragma unroll
+  for (int l = 1; l < PYR_MAX_LEVELS; ++l)
+    if (l < a.n_levels && ((f >> (PYR_FIELD * (l - 1))) & 1ULL)) {
+      const int cell = a.lv[l].cell;
+      const int x = floor_to_cell(c.y, cell), y = floor_to_cell(c.z, cell), z = floor_to_cell(c.w, cell);
+      const int32_t o = (int32_t)((p >> (PYR_FIELD * (l - 1))) & ((1ULL << PYR_FIELD) - 1));
+      reinterpret_cast<int4*>(a.lv[l].coords)[o] = make_int4(c.x, x, y, z);
+      const uint64_t key = pack_key(c.x, x, y, z);
+      uint64_t slot = hash64(key) & a.lv[l].mask;
+      while (a.lv[l].keys[slot] != key) slot = (slot + 1) & a.lv[l].mask;
+      a.lv[l].vals[slot] = o;   // exactly one row per key reaches here
+    }
+}
+
+// per-sample segments of every level in one launch: grid.y = level; rows of level l >= 1 are counted on the device
+__global__ __launch_bounds__(256) void k_pyr_segments(const int32_t* __restrict__ coords0, int64_t n0, const PyrArgs a) {
+  const int l = blockIdx.y;
+  if (l >= a.n_levels || !a.lv[l].seg) return;
+  const int32_t* coords = l == 0 ? coords0 : a.lv[l].coords;
+  const int64_t n = l == 0 ? n0 : (int64_t)a.counts[l];
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= n) return;
+  int32_t* seg = a.lv[l].seg;
+  const int b = coords[4 * i];
+  const int prev = i > 0 ? coords[4 * (i - 1)] : -1;
+  if (b < prev || b >= a.n_batch || b < 0) {
+    atomicOr(&a.status[2 + 2 * l], 1);  // not grouped by sample (or more samples than announced): the global-table path
+    return;
+  }
+  for (int bb = prev + 1; bb <= b; ++bb) seg[bb] = (int32_t)i;
+  if (i == n - 1)
+    for (int bb = b + 1; bb <= a.n_batch; ++bb) seg[bb] = (int32_t)n;
+}
+
 // One thread per (out row, k): probe the in-map.  Offsets: k = (dx+1) + 3(dy+1) + 9(dz+1).
 __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_out, int kvol,
                             int step, int sign, const uint64_t* __restrict__ keys,
@@ -1014,6 +1143,133 @@ int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coord
     }
   }
   *out = m;
+  return CS_OK;
+}
+
+/* All coordinate levels of a batch: out[0] = the map cs_coordmap_create(d_coords, n, tensor_stride) returns, out[l] =
+ * cs_coordmap_stride(out[l - 1], 2) -- the same coordinates, row order and tables -- made from the stride-1 rows in one pass
+ * with ONE host wait (see k_pyr_insert).  n_batch > 0: rows are announced to be grouped by sample with batch indices
+ * < n_batch, and the per-sample segments of every level are made in the same pass (a violated announcement only costs the
+ * LDS kernel-map path, never correctness).  Batches of 2^21 rows or more take the chained calls. */
+int cs_coordmap_pyramid(const int32_t* d_coords, int64_t n, int tensor_stride, int n_levels, int n_batch, void* stream,
+                        cs_coordmap** out) {
+  CS_REQUIRE(out && n_levels >= 1 && n_levels <= PYR_MAX_LEVELS, CS_ERR_INVALID, "cs_coordmap_pyramid: bad arguments");
+  for (int l = 0; l < n_levels; ++l) out[l] = nullptr;
+  CS_REQUIRE(n >= 0 && n < (1LL << 30), CS_ERR_INVALID, "cs_coordmap_pyramid: bad row count %lld", (long long)n);
+  CS_REQUIRE(n == 0 || d_coords, CS_ERR_INVALID, "cs_coordmap_pyramid: coords is NULL");
+  CS_REQUIRE(tensor_stride >= 1, CS_ERR_INVALID, "cs_coordmap_pyramid: bad tensor stride");
+  static const bool chained = getenv("CS_PYRAMID") && getenv("CS_PYRAMID")[0] == '0';
+  if (n == 0 || n >= (1LL << PYR_FIELD) || chained) {
+    int rc = cs_coordmap_create(d_coords, n, tensor_stride, stream, &out[0]);
+    for (int l = 1; l < n_levels && rc == CS_OK; ++l) rc = cs_coordmap_stride(out[l - 1], 2, stream, &out[l]);
+    if (rc != CS_OK)
+      for (int l = 0; l < n_levels; ++l) {
+        cs_coordmap_free(out[l]);
+        out[l] = nullptr;
+      }
+    return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  pool_use_stream(s);
+  ProfScope prof("kmap", s);
+  if (n_batch > 65536) n_batch = 0;
+  cs_coordmap* m[PYR_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  auto fail = [&](int code) {
+    for (int l = 0; l < n_levels; ++l) cs_coordmap_free(m[l]);
+    return code;
+  };
+  PyrArgs a;
+  a.n_levels = n_levels;
+  a.n_batch = n_batch;
+  PoolBuf<int> status(2 + 2 * PYR_MAX_LEVELS);
+  PoolBuf<int32_t> counts(PYR_MAX_LEVELS);
+  PoolBuf<unsigned long long> flag(n), pos(n);
+  if (!status.p || !counts.p || !flag.p || !pos.p) {
+    set_error("cs_coordmap_pyramid: scratch allocation failed");
+    return CS_ERR_HIP;
+  }
+  a.status = status.p;
+  a.counts = counts.p;
+  for (int l = 0; l < n_levels; ++l) {
+    m[l] = new cs_coordmap();
+    m[l]->tensor_stride = tensor_stride << l;
+    // (the coarse levels have at most n rows: tables and coordinate arrays are sized for that)
+    const int rc = alloc_table(m[l], n, s);
+    if (rc != CS_OK) return fail(rc);
+    m[l]->d_coords = (int32_t*)pool_alloc((size_t)n * 4 * sizeof(int32_t));
+    if (n_batch > 0) m[l]->d_seg = (int32_t*)pool_alloc((size_t)(n_batch + 1) * sizeof(int32_t));
+    if (!m[l]->d_coords || (n_batch > 0 && !m[l]->d_seg)) {
+      set_error("cs_coordmap_pyramid: coordinate allocation failed");
+      return fail(CS_ERR_HIP);
+    }
+    a.lv[l].keys = m[l]->d_keys;
+    a.lv[l].vals = m[l]->d_vals;
+    a.lv[l].mask = m[l]->capacity - 1;
+    a.lv[l].coords = m[l]->d_coords;
+    a.lv[l].seg = m[l]->d_seg;
+    a.lv[l].cell = tensor_stride << l;
+  }
+  hipError_t e = hipMemcpyAsync(m[0]->d_coords, d_coords, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(status.p, 0, sizeof(int) * (2 + 2 * PYR_MAX_LEVELS), s);
+  if (e == hipSuccess) e = hipMemsetAsync(counts.p, 0, sizeof(int32_t) * PYR_MAX_LEVELS, s);
+  for (int l = 0; l < n_levels && e == hipSuccess && n_batch > 0; ++l)
+    e = hipMemsetAsync(m[l]->d_seg, 0, (size_t)(n_batch + 1) * sizeof(int32_t), s);
+  if (e != hipSuccess) {
+    set_error("cs_coordmap_pyramid: %s", hipGetErrorString(e));
+    return fail(CS_ERR_HIP);
+  }
+  const unsigned g = (unsigned)ceil_div(n, 256);
+  // level 0's cell is 1 in units of its own stride: its key is the coordinate itself
+  PyrArgs a_ins = a;
+  a_ins.lv[0].cell = 1;
+  hipLaunchKernelGGL(k_pyr_insert, dim3(g), dim3(256), 0, s, m[0]->d_coords, n, a_ins);
+  if (n_levels > 1) {
+    hipLaunchKernelGGL(k_pyr_flag, dim3(g), dim3(256), 0, s, m[0]->d_coords, n, a, flag.p);
+    size_t tmp_bytes = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag.p, pos.p, (int)n, s);
+    PoolBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess && !tmp.p) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, flag.p, pos.p, (int)n, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_pyr_emit, dim3(g), dim3(256), 0, s, m[0]->d_coords, n, a, flag.p, pos.p);
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess && n_batch > 0) {
+    hipLaunchKernelGGL(k_pyr_segments, dim3(g, (unsigned)n_levels), dim3(256), 0, s, m[0]->d_coords, n, a);
+    e = hipGetLastError();
+  }
+  int h_status[2 + 2 * PYR_MAX_LEVELS] = {0};
+  int32_t h_counts[PYR_MAX_LEVELS] = {0};
+  if (e == hipSuccess) e = download_async(h_status, status.p, sizeof(h_status), s);
+  if (e == hipSuccess) e = download_async(h_counts, counts.p, sizeof(h_counts), s);
+  if (e == hipSuccess) e = download_sync(s);
+  if (e != hipSuccess) {
+    set_error("cs_coordmap_pyramid: %s", hipGetErrorString(e));
+    return fail(CS_ERR_HIP);
+  }
+  if (h_status[0]) {
+    set_error("cs_coordmap_create: coordinate out of the supported range (|x|,|y|,|z| < 32768, 0 <= batch < 65536)");
+    return fail(CS_ERR_RANGE);
+  }
+  if (h_status[1]) {
+    set_error("cs_coordmap_create: %d duplicate coordinate rows (quantise the cloud first)", h_status[1]);
+    return fail(CS_ERR_DUPLICATE);
+  }
+  for (int l = 0; l < n_levels; ++l) {
+    m[l]->n = l == 0 ? n : (int64_t)h_counts[l];
+    if (n_batch > 0) {
+      if (h_status[2 + 2 * l] == 0) {
+        m[l]->n_batch = n_batch;
+        m[l]->seg_state = 1;
+      } else {                      // not grouped by sample: the global-table path serves this map
+        pool_free(m[l]->d_seg);
+        m[l]->d_seg = nullptr;
+        m[l]->seg_state = -1;
+      }
+    }
+    out[l] = m[l];
+  }
   return CS_OK;
 }
 

@@ -47,11 +47,10 @@ def fold_bn(sd, prefix, eps=BN_EPS):
 class BatchMaps:
     """Coordinate maps (tensor strides 1, 2, 4, 8) and the kernel maps of one input batch."""
 
-    def __init__(self, coords):
-        self.c1 = B.CoordMap.create(coords, 1)
-        self.c2 = self.c1.stride(2)
-        self.c4 = self.c2.stride(2)
-        self.c8 = self.c4.stride(2)
+    def __init__(self, coords, n_batch=0):
+        # all four coordinate levels in one library call (one host wait); n_batch = the collated batch size when the
+        # caller knows it (rows grouped by sample): the per-sample segments then come out of the same pass
+        self.c1, self.c2, self.c4, self.c8 = B.CoordMap.pyramid(coords, 4, n_batch)
         c1, c2, c4, c8 = self.c1, self.c2, self.c4, self.c8
         names = ("s1", "s1_s2", "s2", "s2_s4", "s4", "s4_s8", "s8", "s8_s4_T", "s4_s2_T", "s2_s1_T")
         specs = [(c1, c1), (c1, c2), (c2, c2), (c2, c4), (c4, c4), (c4, c8), (c8, c8),
@@ -119,11 +118,11 @@ class ResUNetEngine:
         s, b = self.bn[norm]
         return B.conv_fwd(km, x, self.w[conv], s, b, None, False)
 
-    def forward(self, coords, feats, maps=None):
-        """coords int32 [N,4] (batch,x,y,z) unique; feats f32 [N,1].
-        Returns (out [N,16] unit rows, feat [N8,256], maps)."""
+    def forward(self, coords, feats, maps=None, n_batch=0):
+        """coords int32 [N,4] (batch,x,y,z) unique; feats f32 [N,1]; n_batch: number of samples of a collated batch (rows
+        grouped by sample) when known.  Returns (out [N,16] unit rows, feat [N8,256], maps)."""
         if maps is None:
-            maps = BatchMaps(coords)
+            maps = BatchMaps(coords, n_batch)
         m = maps
         dev = feats.device
         n1, n2, n4 = m.c1.n, m.c2.n, m.c4.n

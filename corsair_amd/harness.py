@@ -84,7 +84,7 @@ class Pipeline:
         keep, grid, out_off = B.voxelize(xyz, offsets, voxel_size)
         origin = xyz[keep].to(torch.float32)
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=xyz.device)
-        out, feat8, maps = self.engine.forward(grid, feats)
+        out, feat8, maps = self.engine.forward(grid, feats, n_batch=len(offsets) - 1)
         return EmbeddedSet(out, origin, out_off, self._descriptors(feat8, maps, len(offsets) - 1))
 
     def _descriptors(self, feat8, maps, n):
@@ -112,7 +112,7 @@ class Pipeline:
             base += len(offsets) - 1
         grid = torch.cat(grids)
         feats = torch.ones((grid.shape[0], 1), dtype=torch.float32, device=grid.device)
-        out, feat8, maps = self.engine.forward(grid, feats)
+        out, feat8, maps = self.engine.forward(grid, feats, n_batch=base)
         return EmbeddedSet(out, torch.cat(origins), out_off, self._descriptors(feat8, maps, base))
 
     def embed_clouds(self, clouds, batch_size=None):

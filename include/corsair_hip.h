@@ -62,6 +62,14 @@ int cs_device_count(void);
 int cs_coordmap_create(const int32_t* d_coords, int64_t n, int tensor_stride, void* stream,
                        cs_coordmap** out);
 int cs_coordmap_stride(const cs_coordmap* in, int stride, void* stream, cs_coordmap** out);
+/* All coordinate levels a network will ask for, at once (ME's coordinate manager makes the strided maps one by one as
+ * model/resunet.py:64-103 reaches each stride-2 convolution): out[0] = cs_coordmap_create(d_coords, n, tensor_stride),
+ * out[l] = cs_coordmap_stride(out[l-1], 2) for l < n_levels <= 4 -- identical coordinates, row order and tables, built from
+ * the stride-1 rows in one pass with one host wait.  n_batch > 0 announces rows grouped by sample with batch indices
+ * < n_batch (sparse_collate's order, utils/Info/CADLib.py:148-178): the per-sample segments the LDS kernel-map path uses are
+ * then made in the same pass (n_batch <= 0: on first use, as for cs_coordmap_create). */
+int cs_coordmap_pyramid(const int32_t* d_coords, int64_t n, int tensor_stride, int n_levels, int n_batch, void* stream,
+                        cs_coordmap** out);
 int64_t cs_coordmap_size(const cs_coordmap* m);
 int cs_coordmap_tensor_stride(const cs_coordmap* m);
 const int32_t* cs_coordmap_coords(const cs_coordmap* m); /* device int32 [n,4] */

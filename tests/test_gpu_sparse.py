@@ -236,3 +236,46 @@ def test_conv_split_experiment_close_to_exact_chain(gpu, oracle_native, monkeypa
             worst = float((np.abs(g - e) / bound).max())
             assert worst <= 1.0, f"cin {cin} cout {cout} case {i}: diff / bound = {worst}"
         assert any(not np.array_equal(g, e) for g, e in zip(got, exact))   # the experiment really ran
+
+
+@pytest.mark.parametrize("hint", [0, 5, 3, 70000])
+def test_coordmap_pyramid_equals_chained_calls(gpu, hint):
+    """cs_coordmap_pyramid (all four coordinate levels from the stride-1 rows in one pass, one host wait) returns the maps of
+    cs_coordmap_create + three chained cs_coordmap_stride(2) calls: same coordinates in the same (first-occurrence) order,
+    same tables (the kernel maps built on them are identical, entry for entry).  hint = announced batch size: 0 (none), the
+    true one, one that is too small (the announcement is violated: only the LDS path is lost) and one beyond the limit.
+    The batch has an empty sample; a second batch has its rows shuffled (not grouped by sample)."""
+    from corsair_amd import backend as B
+
+    coords, _, _, _ = make_batch([21, 22, 23, 24], n_points=5000)
+    coords[coords[:, 0] == 3, 0] = 4          # sample 3 is empty, batch indices 0, 1, 2, 4
+    rng = np.random.default_rng(4)
+    for rows in (coords, coords[rng.permutation(len(coords))]):
+        g = torch.from_numpy(np.ascontiguousarray(rows)).to(gpu)
+        c1 = B.CoordMap.create(g, 1)
+        chain = [c1, c1.stride(2)]
+        chain.append(chain[-1].stride(2))
+        chain.append(chain[-1].stride(2))
+        pyr = B.CoordMap.pyramid(g, 4, hint)
+        for a, b in zip(chain, pyr):
+            assert a.n == b.n and a.tensor_stride == b.tensor_stride
+            assert torch.equal(a.coords, b.coords)
+        specs = lambda c: [(c[0], c[0]), (c[0], c[1]), (c[1], c[1]), (c[1], c[2]), (c[2], c[2]), (c[2], c[3]), (c[3], c[3]),
+                           (c[3], c[2], 3, True), (c[2], c[1], 3, True), (c[1], c[0], 3, True)]
+        for ka, kb in zip(B.KernelMap.build_many(specs(chain)), B.KernelMap.build_many(specs(pyr))):
+            assert ka.num_pairs == kb.num_pairs and torch.equal(ka.table(), kb.table())
+    two = B.CoordMap.pyramid(torch.from_numpy(coords).to(gpu), 2, 5)
+    assert len(two) == 2 and two[1].n == chain[1].n
+
+
+def test_coordmap_pyramid_refuses_what_create_refuses(gpu):
+    from corsair_amd import _lib, backend as B
+
+    dup = torch.tensor([[0, 1, 2, 3], [0, 4, 5, 6], [0, 1, 2, 3]], dtype=torch.int32, device=gpu)
+    with pytest.raises(_lib.CorsairHipError, match="duplicate"):
+        B.CoordMap.pyramid(dup, 4, 1)
+    far = torch.tensor([[0, 1, 2, 3], [0, 40000, 5, 6]], dtype=torch.int32, device=gpu)
+    with pytest.raises(_lib.CorsairHipError, match="range"):
+        B.CoordMap.pyramid(far, 4, 1)
+    empty = B.CoordMap.pyramid(torch.zeros((0, 4), dtype=torch.int32, device=gpu), 4, 0)
+    assert [m.n for m in empty] == [0, 0, 0, 0]

@@ -26,18 +26,18 @@ def timed(fn, n):
     e1.record(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3, e0.elapsed_time(e1) / n, r
 
-maps = engine.BatchMaps(grid)
+maps = engine.BatchMaps(grid, n_cl)
 pairs = maps.total_pairs()
 print("%s batch: %d clouds, rows s1/s2/s4/s8 = %d / %d / %d / %d, pairs %d" % (
     kind, n_cl, maps.c1.n, maps.c2.n, maps.c4.n, maps.c8.n, sum(pairs.values())))
 chk = sum(int(getattr(maps, k).table().to(torch.int64).sum()) for k in pairs)
 for rep in range(3):
-    wall, gpu, _ = timed(lambda: engine.BatchMaps(grid), reps)
+    wall, gpu, _ = timed(lambda: engine.BatchMaps(grid, n_cl), reps)
     print("maps: %.3f ms wall, %.3f ms event time per batch" % (wall, gpu))
 if len(sys.argv) > 3 and sys.argv[3] == "maps-only":      # (under rocprofv3: only the map construction in the trace)
     sys.exit(0)
 _lib.prof_reset(); _lib.prof_enable(True)
-wall, gpu, _ = timed(lambda: eng.forward(grid, feats), reps)
+wall, gpu, _ = timed(lambda: eng.forward(grid, feats, n_batch=n_cl), reps)
 _lib.prof_enable(False)
 print("forward incl. maps: %.3f ms wall, %.3f ms event time; families (ms per forward): kmap %.3f, conv %.3f" % (
     wall, gpu, _lib.prof_get("kmap")[0] / reps, _lib.prof_get("conv")[0] / reps))
