@@ -2066,7 +2066,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
           const int s2_pslots = cur.pslots;
           const int32_t* s2_xcd_prob = cur.xcd_prob;
           const XcdTab& s2_xtab = cur.xtab;
-          if (run_s2) {
+          // CS_RANSAC_KNOCKOUT (TIMING EXPERIMENT ONLY, results are wrong): bit 0 skips the exact count of the survivors, bit 1
+          // the second-stage launch -- what a perfect bound in front of them could save at most (profiles/r5f_*)
+          static const int knockout = getenv("CS_RANSAC_KNOCKOUT") ? atoi(getenv("CS_RANSAC_KNOCKOUT")) : 0;
+          if (run_s2 && !(knockout & 2)) {
             // K = 32 bound of the survivors (rows compacted by k_ransac_survivors): one small prefilter launch over all
             // pairs, then the list filtered again
             // tiles for the WHOLE capacity: this round's survivor counts are not known on the host (surv_cap comes from the
@@ -2090,9 +2093,10 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
               list_n = n_surv2.p;
             }
           }
-          hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
-                             d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, list_p, list_n, list_stride,
-                             list_cnt2);
+          if (!(knockout & 1))
+            hipLaunchKernelGGL(k_ransac_count_few, dim3((unsigned)fslices, (unsigned)n_prob, (unsigned)fslots), dim3(256), 0, s,
+                               d_probs, pk.p, tot1, hyp_r, bmax, thr2, scale, res_cnt.p, cand_err.p, list_p, list_n, list_stride,
+                               (knockout & 2) ? (const int32_t*)nullptr : list_cnt2);
           err_known = true;
         } else {
           const int ltiles = tiles < 4 ? tiles : 4;  // tile slots; the kernel strides over longer lists

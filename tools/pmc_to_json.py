@@ -4,6 +4,10 @@ and a text table of every library kernel.  Corrections as MI355X_MICROARCH.md pr
 KiB; on gfx950 FETCH_SIZE tallies 16-B/lane streaming reads at half their bytes, so kernels that stream through
 LDS-DMA or dwordx4 loads (listed in WIDE) get FETCH doubled; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are
 quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; utilisation = busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
+`valu_active` (round 5): the share of SIMD cycles the VECTOR ALU is busy = 2 cycles per wave64 instruction
+(the SIMD-32 datapath, MI355X_MICROARCH.md cycle table) x SQ_ACTIVE_INST_VALU (one quad-cycle of issue per instruction =
+the instruction count) / SIMD cycles.  Rounds 1-4 charged the 4 ISSUE cycles of an instruction instead: the waves of a SIMD
+overlap their issue slots, so that figure exceeded 1 (1.08 on the table workload) and could not be added to `mfma_busy`.
 
 The file carries `csrc_sha` (hash of corsair_amd/csrc sources at collection time): bench.py attaches the counters
 only while the kernels are unchanged, otherwise it prints traffic: null and counters: "stale" (ADVICE r2)."""
@@ -22,8 +26,10 @@ DOM_MATCH = {"k_ransac_prefilter": ("k_ransac_prefilterILi1", "k_ransac_prefilte
 FAMILY = {
     "conv": (("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic"), ("k_conv_dma", "k_conv_mfma", "k_conv_stem", "k_conv_generic")),
     # one "kmap" profile scope per kernel map (its build kernel) + one per batch for the common tiling-order pass
-    "kmap": (("k_build_nbr", "k_row_keys", "k_sorted_tables", "k_insert", "k_emit_strided", "k_flag_first", "k_segments", "k_fill_table"),
-             ("k_build_nbr_lds", "k_build_nbr(", "k_row_keys")),
+    # (round 5: one "kmap" scope for the coordinate pyramid, one for the level kernels, one for the tiling order of a batch)
+    "kmap": (("k_level_maps", "k_build_nbr", "k_row_keys", "k_order_finish", "k_pyr_", "k_insert", "k_emit_strided", "k_flag_first",
+              "k_segments", "k_fill_table"),
+             ("k_pyr_insert", "k_order_finish")),
     "knn": (("k_knn_f16", "k_knn_rescore_f16", "k_knf_pack", "k_knn_feat"), ("k_knf_pack_queries",)),
     "chamfer": (("k_chamfer",), ("k_chamfer_mfma", "k_chamfer<")),
     "topk": (("k_topk", "k_tkf", "k_dist_matrix", "k_row_topk"), ("k_topk_finish",)),
@@ -76,7 +82,7 @@ for k in sorted(set(fa) | set(sa)):
     gui = s.get("GRBM_GUI_ACTIVE", 0.0)
     simd_cycles = 1024.0 * gui / 8.0
     mfma = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles if simd_cycles else 0.0
-    valu = 4.0 * s.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles if simd_cycles else 0.0
+    valu = 2.0 * s.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles if simd_cycles else 0.0
     wave = s.get("SQ_WAVE_CYCLES", 0.0)
     wait_any = s.get("SQ_WAIT_ANY", 0.0) / wave if wave else 0.0
     wait_inst = s.get("SQ_WAIT_INST_ANY", 0.0) / wave if wave else 0.0
@@ -87,7 +93,7 @@ rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
 with open(f"{out}/pmc_table.txt", "w") as f:
     f.write("# tools/pmc_collect.sh: rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ set} -- python3 bench.py "
             + " ".join(sys.argv[2:]) + " --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-probe --no-solo-probe --no-extra-workloads\n")
-    f.write("# hbm = (2x for 16-B/lane streaming kernels) FETCH_SIZE + WRITE_SIZE per launch; mfma_busy / valu_active = share of SIMD cycles;\n"
+    f.write("# hbm = (2x for 16-B/lane streaming kernels) FETCH_SIZE + WRITE_SIZE per launch; mfma_busy = matrix pipe, valu = vector ALU (2 cycles per wave64 instruction): shares of SIMD cycles;\n"
             "# wait_any / wait_inst = share of wave cycles parked (waitcnt, barrier) / stalled at issue\n")
     f.write(f"{'kernel':46s} {'launches':>8s} {'hbm MB/launch':>14s} {'mfma_busy':>9s} {'valu':>6s} {'wait_any':>8s} {'wait_inst':>9s} {'kcycles':>8s}\n")
     for r in rows:
