@@ -65,6 +65,7 @@ def _declare(lib):
                                     c_uint64, vp, vp, vp, vp, vp]),
         "cs_ransac_prefilter_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_knn_shortlist_stats": (None, [POINTER(c_uint64), c_int]),
+        "cs_chamfer_f16_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_l2_topk_stats": (None, [POINTER(c_uint64), c_int]),
         "cs_topk_catalog_create": (c_int, [vp, c_int64, c_int, vp, POINTER(vp)]),
         "cs_l2_topk_catalog": (c_int, [vp, c_int64, vp, c_int, vp, vp, c_int, vp]),

@@ -1524,9 +1524,12 @@ __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restr
                                                       const float* __restrict__ tgt,
                                                       const double* __restrict__ t4g,
                                                       const float* __restrict__ T, int reduce_max,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial,
+                                                      // != nullptr: only the tiles the f16 kernel could not vouch for
+                                                      const int32_t* __restrict__ only_flagged) {
   __shared__ __attribute__((aligned(16))) double t4[CHM_TT * 4];
   __shared__ double red[CHM_ST];
+  if (only_flagged && !only_flagged[blockIdx.x]) return;
   const ChamferWork wk = work[blockIdx.x];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1601,6 +1604,251 @@ __global__ __launch_bounds__(256) void k_chamfer_mfma(const ChamferWork* __restr
   if (tid == 0) partial[wk.slot] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------
+// The same search on the f16 matrix cores (round 5).  The f64 matrix pipe of gfx950 is the vector unit's double-precision
+// ALU (78.6 TF either way): k_chamfer_mfma sits at 0.23 of it with five VALU operations per result on top.  The ranking
+// value |t|^2 - 2 p.t needs nine products when the coordinates are cut into f16 hi + lo (ph.th + ph.tl + pl.th): ONE
+// v_mfma_f32_32x32x16_f16 per 32 targets x 32 sources with |t|^2 in the accumulator input, 16x the rate per pair.  It only
+// RANKS: a lane (one source, 16 of a tile's 32 target rows) keeps the two best TILE minima and the third best value (eight
+// v_min3 per tile, no index per value); at the end the rows of its two tiles are evaluated with the canonical f64 chain,
+// and the result is vouched for when it lies below the third value minus the error budget of the approximation -- then no
+// row outside the evaluated tiles can be nearer.  A workgroup with a source that fails the test is recomputed by
+// k_chamfer_mfma (flag array, no host decision).  Coordinates are scaled by 2^9 before the cut so that the lo parts stay
+// normal f16 numbers; |coordinate| >= 60 does not fit and takes the f64 kernel as well.  Results: the same canonical
+// distances as the other two kernels (tests/test_gpu_post.py::test_chamfer_matches_oracle, all three paths).
+constexpr int CHF_PITCH = 24;     // halfs per image row (48 B: conflict-free ds_read_b128 fragments)
+constexpr int CHF_ROWS = 256;     // target rows per LDS stage (8 MFMA row tiles)
+constexpr int CHF_NG = 2;         // 32-source groups per wave
+constexpr float CHF_SCALE = 512.0f;
+static_assert(4 * 32 * CHF_NG == CHM_ST, "the f16 kernel and its f64 fallback share the work items");
+
+// target image: row j = [th(3) | tl(3) | th(3) | 0(7) | pad(8)] of the scaled coordinates, tn32[j] = |S t|^2 (f64 chain,
+// rounded to f32); rows [n, n_pad) are zero with tn32 = +inf (they never win)
+__global__ void k_chamfer_pack16(const float* __restrict__ tgt, int64_t n, int64_t n_pad, _Float16* __restrict__ img,
+                                 float* __restrict__ tn32, float4* __restrict__ t4f) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  union {
+    _Float16 h[CHF_PITCH];
+    uint4 v[3];
+  } row;
+#pragma unroll
+  for (int c = 0; c < CHF_PITCH; ++c) row.h[c] = (_Float16)0.0f;
+  float t2 = INFINITY;
+  if (i < n) {
+    // (x, y, z, 0) in one 16-byte row: the final canonical evaluation reads a candidate row with ONE request instead of three
+    t4f[i] = make_float4(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], 0.0f);
+    double n2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = tgt[3 * i + c] * CHF_SCALE;     // exact (power of two) unless it overflows, which the kernel flags
+      _Float16 hi, lo;
+      knf_split(v, &hi, &lo);
+      row.h[c] = hi;
+      row.h[3 + c] = lo;
+      row.h[6 + c] = hi;
+      n2 = fma((double)v, (double)v, n2);
+    }
+    t2 = (float)n2;
+  }
+  uint4* dst = reinterpret_cast<uint4*>(img + i * CHF_PITCH);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[c] = row.v[c];
+  tn32[i] = t2;
+}
+
+__global__ __launch_bounds__(256) void k_chamfer_f16(const ChamferWork* __restrict__ work, const float* __restrict__ src,
+                                                     const float4* __restrict__ t4f, const _Float16* __restrict__ img,
+                                                     const float* __restrict__ tn32, const float* __restrict__ T,
+                                                     int reduce_max, double* __restrict__ partial,
+                                                     int32_t* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) _Float16 a_s[2][CHF_ROWS * CHF_PITCH];
+  __shared__ __attribute__((aligned(16))) float tn_s[2][CHF_ROWS];
+  __shared__ double red[CHM_ST];
+  __shared__ float wmax[4];
+  __shared__ int wg_bad;
+  const ChamferWork wk = work[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int col = lane & 31;
+  const float* Tp = T + (int64_t)wk.prob * 16;
+  if (tid == 0) wg_bad = 0;
+  double px[CHF_NG], py[CHF_NG], pz[CHF_NG];
+  f16x8 bop[CHF_NG];
+  float b1[CHF_NG], b2[CHF_NG], b3[CHF_NG];
+  int t1[CHF_NG], t2[CHF_NG];
+  bool in_range = true;
+#pragma unroll
+  for (int g = 0; g < CHF_NG; ++g) {
+    const int sloc = wave * 32 * CHF_NG + 32 * g + col;
+    const float* sp = src + (wk.s0 + (sloc < wk.sn ? sloc : 0)) * 3;
+    const double x = sp[0], y = sp[1], z = sp[2];
+    px[g] = fma((double)Tp[0], x, fma((double)Tp[1], y, fma((double)Tp[2], z, (double)Tp[3])));
+    py[g] = fma((double)Tp[4], x, fma((double)Tp[5], y, fma((double)Tp[6], z, (double)Tp[7])));
+    pz[g] = fma((double)Tp[8], x, fma((double)Tp[9], y, fma((double)Tp[10], z, (double)Tp[11])));
+    const float pf[3] = {(float)px[g] * CHF_SCALE, (float)py[g] * CHF_SCALE, (float)pz[g] * CHF_SCALE};
+    _Float16 hi[3], lo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      knf_split(-2.0f * pf[c], &hi[c], &lo[c]);
+      in_range = in_range && fabsf(pf[c]) < 60.0f * CHF_SCALE;   // (NaN fails too)
+    }
+    // B rows k: 0..2 = -2 ph (x th), 3..5 = -2 ph (x tl), 6..8 = -2 pl (x th), 9..15 = 0; this lane holds k = 8 half .. + 7
+    const _Float16 z0 = (_Float16)0.0f;
+    if (half == 0)
+      bop[g] = f16x8{hi[0], hi[1], hi[2], hi[0], hi[1], hi[2], lo[0], lo[1]};
+    else
+      bop[g] = f16x8{lo[2], z0, z0, z0, z0, z0, z0, z0};
+    b1[g] = b2[g] = b3[g] = INFINITY;
+    t1[g] = t2[g] = -1;
+  }
+  // register-staged double buffer: the next stage's 12 KiB image + |t|^2 are requested before this stage is computed
+  const uint4* gimg = reinterpret_cast<const uint4*>(img + (int64_t)wk.t0 * CHF_PITCH);
+  constexpr int U4_PER_STAGE = CHF_ROWS * CHF_PITCH * 2 / 16;   // 768 = 3 per thread
+  uint4 st0, st1, st2;     // (three named registers: an array captured by the lambdas below went to scratch)
+  float stn;
+  float tmax2 = 0.0f;
+  auto load_stage = [&](int base) {
+    const uint4* g = gimg + (int64_t)base * (CHF_PITCH * 2 / 16) + tid;
+    st0 = g[0];
+    st1 = g[256];
+    st2 = g[512];
+    const int r = base + tid;
+    stn = r < wk.tn ? tn32[wk.t0 + r] : INFINITY;   // rows past the segment (another problem's rows) never win
+    if (r < wk.tn) tmax2 = fmaxf(tmax2, stn);
+  };
+  auto store_stage = [&](int b) {
+    uint4* d = reinterpret_cast<uint4*>(a_s[b]) + tid;
+    d[0] = st0;
+    d[256] = st1;
+    d[512] = st2;
+    tn_s[b][tid] = stn;
+  };
+  static_assert(U4_PER_STAGE == 3 * 256, "three 16-byte pieces per thread");
+  if (wk.tn > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  int buf = 0;
+  for (int base = 0; base < wk.tn; base += CHF_ROWS) {
+    __syncthreads();
+    const bool more = base + CHF_ROWS < wk.tn;
+    if (more) load_stage(base + CHF_ROWS);
+#pragma unroll 1
+    for (int t = 0; t < CHF_ROWS / 32; ++t) {
+      if (base + 32 * t >= wk.tn) break;   // whole tile past the range (block-uniform)
+      const f16x8 a = *reinterpret_cast<const f16x8*>(a_s[buf] + (t * 32 + col) * CHF_PITCH + 8 * half);
+      f32x16 c16;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 v = *reinterpret_cast<const float4*>(&tn_s[buf][t * 32 + 8 * q4 + 4 * half]);
+        c16[4 * q4 + 0] = v.x; c16[4 * q4 + 1] = v.y; c16[4 * q4 + 2] = v.z; c16[4 * q4 + 3] = v.w;
+      }
+      const int tile = base / 32 + t;
+#pragma unroll
+      for (int g = 0; g < CHF_NG; ++g) {
+        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop[g], c16, 0, 0, 0);
+        float m = fminf(fminf(d[0], d[1]), d[2]);
+        m = fminf(fminf(m, d[3]), d[4]);
+        m = fminf(fminf(m, d[5]), d[6]);
+        m = fminf(fminf(m, d[7]), d[8]);
+        m = fminf(fminf(m, d[9]), d[10]);
+        m = fminf(fminf(m, d[11]), d[12]);
+        m = fminf(fminf(m, d[13]), d[14]);
+        m = fminf(m, d[15]);
+        const bool hit = m < b3[g];
+        if (__any(hit)) {
+          if (hit) {
+            if (m < b2[g]) {
+              b3[g] = b2[g];
+              if (m < b1[g]) {
+                b2[g] = b1[g];
+                t2[g] = t1[g];
+                b1[g] = m;
+                t1[g] = tile;
+              } else {
+                b2[g] = m;
+                t2[g] = tile;
+              }
+            } else {
+              b3[g] = m;
+            }
+          }
+        }
+      }
+    }
+    if (more) store_stage(buf ^ 1);
+    buf ^= 1;
+  }
+  // largest |S t|^2 of the segment (error budget)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, off));
+  if (lane == 0) wmax[wave] = tmax2;
+  __syncthreads();
+  const double tmax = sqrt((double)fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))) / (double)CHF_SCALE;
+  bool bad = !in_range || !(tmax < 60.0);
+  const float4* trow = t4f + wk.t0;
+  auto eval_tile = [&](int g, int tile) {   // canonical distances of this lane's 16 rows of a tile: smallest
+    double e = INFINITY;
+    if (tile >= 0) {
+      float4 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = tile * 32 + 4 * half + (i & 3) + 8 * (i >> 2);
+        v[i] = trow[row < wk.tn ? row : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = tile * 32 + 4 * half + (i & 3) + 8 * (i >> 2);
+        const double dx = px[g] - (double)v[i].x, dy = py[g] - (double)v[i].y, dz = pz[g] - (double)v[i].z;
+        const double d = fma(dz, dz, fma(dy, dy, dx * dx));
+        e = row < wk.tn ? fmin(e, d) : e;
+      }
+    }
+    return e;
+  };
+#pragma unroll
+  for (int g = 0; g < CHF_NG; ++g) {
+    // Every unevaluated row has an approximate value >= the smallest tile minimum that was not evaluated (in scaled units
+    // S^2 (|t|^2 - 2 p.t)), hence an exact one >= that - eps with eps covering: <= 16 f32 accumulation steps relative to
+    // sum |terms| <= (|P| + |T|)^2, the dropped lo.lo products and the hi + lo cut residuals (2^-22 relative each), the f32
+    // rounding of |T|^2 -- together < 2^-20 (|P| + |T|max)^2, charged 2^-19 -- and lo parts below the f16 normal range
+    // should the matrix pipe flush them (<= 2^-14 per product side: 2^-10 (|P| + |T|max) covers all nine).
+    const double pn2 = fma(pz[g], pz[g], fma(py[g], py[g], px[g] * px[g]));
+    const double S = (double)CHF_SCALE, PT = S * (sqrt(pn2) + tmax);
+    const double eps = 0x1.0p-19 * PT * PT + 0x1.0p-10 * PT;
+    // best tile of either lane of the source first; the second tiles only where that does not settle it
+    double e = eval_tile(g, t1[g]);
+    e = fmin(e, __shfl_xor(e, 32));
+    float rest = fminf(b2[g], __shfl_xor(b2[g], 32));     // smallest unevaluated tile minimum of the source
+    bool ok = rest == INFINITY || (e - pn2) * S * S <= (double)rest - eps;
+    if (__any(!ok)) {
+      double e2 = ok ? INFINITY : eval_tile(g, t2[g]);
+      e2 = fmin(e2, __shfl_xor(e2, 32));
+      if (!ok) {
+        e = fmin(e, e2);
+        rest = fminf(b3[g], __shfl_xor(b3[g], 32));
+        ok = rest == INFINITY || (e - pn2) * S * S <= (double)rest - eps;
+      }
+    }
+    const int sloc = wave * 32 * CHF_NG + 32 * g + col;
+    if (sloc < wk.sn && !ok) bad = true;
+    if (half == 0) red[sloc] = sloc < wk.sn ? sqrt(e) : 0.0;
+  }
+  if (__any(bad) && lane == 0) atomicOr(&wg_bad, 1);
+  __syncthreads();
+  for (int off = CHM_ST / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] = reduce_max ? fmax(red[tid], red[tid + off]) : red[tid] + red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    partial[wk.slot] = red[0];
+    flag[blockIdx.x] = wg_bad;
+  }
+}
+
 __global__ void k_chamfer_finish(const double* __restrict__ partial,
                                  const int32_t* __restrict__ slot_begin,
                                  const int64_t* __restrict__ src_count, int n_prob, int reduce_max,
@@ -1633,6 +1881,7 @@ using namespace cs;
 // {queries answered by the f16 shortlist path, of those recomputed exhaustively}; counted only while
 // CS_KNN_STATS=1 (the count costs a synchronisation)
 static std::atomic<unsigned long long> g_knn_stats[2];
+static std::atomic<unsigned long long> g_chamfer_stats[2];
 
 __global__ void k_count_flags(const int32_t* __restrict__ flag, int64_t n, unsigned long long* __restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1648,6 +1897,13 @@ void cs_knn_shortlist_stats(uint64_t out[2], int reset) {
   for (int i = 0; i < 2; ++i) {
     if (out) out[i] = g_knn_stats[i].load();
     if (reset) g_knn_stats[i].store(0);
+  }
+}
+
+void cs_chamfer_f16_stats(uint64_t out[2], int reset) {
+  for (int i = 0; i < 2; ++i) {
+    if (out) out[i] = g_chamfer_stats[i].load();
+    if (reset) g_chamfer_stats[i].store(0);
   }
 }
 
@@ -2125,9 +2381,11 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
   if (n_prob <= 0) return CS_OK;
   hipStream_t s = (hipStream_t)stream;
   pool_use_stream(s);
-  // CS_CHAMFER_MFMA=0 selects the exhaustive all-VALU chain kernel
+  // CS_CHAMFER_MFMA=0 selects the exhaustive all-VALU chain kernel; CS_CHAMFER_F16=0 the f64 matrix-pipe kernel for every
+  // tile (default: the f16 matrix-core ranking, the f64 kernel only for the tiles it flags)
   const char* env = getenv("CS_CHAMFER_MFMA");
   const bool mfma = !(env && env[0] == '0');
+  const bool f16 = mfma && !(getenv("CS_CHAMFER_F16") && getenv("CS_CHAMFER_F16")[0] == '0');
   const int64_t stile = mfma ? CHM_ST : 256;
   std::vector<ChamferWork> work;
   std::vector<int32_t> slot_begin(n_prob + 1, 0);
@@ -2177,8 +2435,40 @@ static int nn_dist_reduce(const float* d_src, const int64_t* h_soff, const float
         if (nt_rows)
           hipLaunchKernelGGL(k_chamfer_pack, dim3((unsigned)ceil_div(nt_rows, 256)), dim3(256), 0, s, d_tgt,
                              nt_rows, t4g.p);
-        hipLaunchKernelGGL(k_chamfer_mfma, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
-                           d_tgt, t4g.p, d_T, reduce_max, partial.p);
+        if (f16) {
+          // image rows padded by one stage: the last stage of the last segment reads past its end
+          const int64_t n_pad = nt_rows + CHF_ROWS;
+          PoolBuf<_Float16> img16((size_t)n_pad * CHF_PITCH);
+          PoolBuf<float> tn16((size_t)n_pad);
+          PoolBuf<float4> t4f((size_t)(nt_rows ? nt_rows : 1));
+          PoolBuf<int32_t> wflag(work.size());
+          if (!img16.p || !tn16.p || !wflag.p || !t4f.p) {
+            set_error("cs_chamfer_1dir: scratch allocation failed");
+            return CS_ERR_HIP;
+          }
+          hipLaunchKernelGGL(k_chamfer_pack16, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, s, d_tgt, nt_rows, n_pad,
+                             img16.p, tn16.p, t4f.p);
+          hipLaunchKernelGGL(k_chamfer_f16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src, t4f.p, img16.p,
+                             tn16.p, d_T, reduce_max, partial.p, wflag.p);
+          hipLaunchKernelGGL(k_chamfer_mfma, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src, d_tgt, t4g.p, d_T,
+                             reduce_max, partial.p, wflag.p);
+          const bool stats = getenv("CS_CHAMFER_STATS") && getenv("CS_CHAMFER_STATS")[0] == '1';
+          if (stats) {   // diagnostics / tests: tiles answered, of those recomputed by the f64 kernel (synchronises)
+            PoolBuf<unsigned long long> cnt(1);
+            unsigned long long h = 0;
+            if (cnt.p && hipMemsetAsync(cnt.p, 0, 8, s) == hipSuccess) {
+              hipLaunchKernelGGL(k_count_flags, dim3((unsigned)ceil_div((int64_t)work.size(), 256)), dim3(256), 0, s, wflag.p,
+                                 (int64_t)work.size(), cnt.p);
+              if (hipMemcpyAsync(&h, cnt.p, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+                g_chamfer_stats[0] += work.size();
+                g_chamfer_stats[1] += h;
+              }
+            }
+          }
+        } else {
+          hipLaunchKernelGGL(k_chamfer_mfma, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,
+                             d_tgt, t4g.p, d_T, reduce_max, partial.p, (const int32_t*)nullptr);
+        }
       }
       else
         hipLaunchKernelGGL(k_chamfer, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_src,

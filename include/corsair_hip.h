@@ -234,6 +234,11 @@ void cs_knn_shortlist_stats(uint64_t out[2], int reset);
  * distance to the nearest target point, writes the mean to d_out[p] (f64).
  * Source / target segments are selected per problem by index into the offset tables.
  * ---------------------------------------------------------------------------------------- */
+/* Diagnostics of the f16 matrix-core ranking inside cs_chamfer_1dir / cs_hausdorff_1dir (default path): {256-source tiles
+ * answered, of those recomputed by the f64 matrix-pipe kernel because a source was within the approximation's error budget
+ * of a tie}, counted only while CS_CHAMFER_STATS=1.  CS_CHAMFER_F16=0: the f64 kernel for everything; CS_CHAMFER_MFMA=0: the
+ * exhaustive all-VALU chain.  All three return the same canonical distances. */
+void cs_chamfer_f16_stats(uint64_t out[2], int reset);
 int cs_chamfer_1dir(const float* d_src, const int64_t* h_soff, const float* d_tgt,
                     const int64_t* h_toff, const int32_t* h_src_seg, const int32_t* h_tgt_seg,
                     int n_prob, const float* d_T, double* d_out, void* stream);

@@ -120,12 +120,17 @@ def test_knn_f16_shortlist_falls_back_on_ties(gpu, oracle_native, monkeypatch):
     assert int(st[0]) == nq and 1 <= int(st[1]) < nq // 4    # some, not most, went through the fallback
 
 
-@pytest.mark.parametrize("mfma", ["1", "0"])
-def test_chamfer_matches_oracle(gpu, oracle_native, monkeypatch, mfma):
-    """f64 matrix-pipe arg-min + canonical re-evaluation (default) and the exhaustive VALU chain."""
+@pytest.mark.parametrize("path", ["f16", "f64", "valu"])
+def test_chamfer_matches_oracle(gpu, oracle_native, monkeypatch, path):
+    """The three kernels behind cs_chamfer_1dir: f16 matrix-core ranking + canonical re-evaluation of the two best tiles per
+    lane + verification (default, round 5), the f64 matrix-pipe arg-min (CS_CHAMFER_F16=0, also the fallback of the first)
+    and the exhaustive VALU chain (CS_CHAMFER_MFMA=0)."""
     from corsair_amd import backend as B, synth
 
-    monkeypatch.setenv("CS_CHAMFER_MFMA", mfma)
+    if path == "f64":
+        monkeypatch.setenv("CS_CHAMFER_F16", "0")
+    elif path == "valu":
+        monkeypatch.setenv("CS_CHAMFER_MFMA", "0")
 
     rng = np.random.default_rng(3)
     clouds = [rng.uniform(-1, 1, (n, 3)).astype(np.float32) for n in (1500, 777, 1, 300)]
@@ -137,6 +142,66 @@ def test_chamfer_matches_oracle(gpu, oracle_native, monkeypatch, mfma):
     for p in range(5):
         want = oracle_native.chamfer_1dir(clouds[src_seg[p]], clouds[tgt_seg[p]], Ts[p])
         assert got[p] == pytest.approx(want, rel=1e-12), p
+
+
+def test_chamfer_f16_ranking_vouches_or_falls_back(gpu, oracle_native, monkeypatch):
+    """The f16 ranking only ANSWERS where its error budget proves the evaluated rows hold the nearest target.  (1) Voxelised
+    real-shaped clouds (the bench's use): the default path equals the f64 kernel bit for bit, and few tiles fall back.
+    (2) Adversarial: every target exists four times within 1e-8 of itself, scattered over the array (so the copies sit in
+    different 32-row tiles): best, second and third candidate tie far inside the budget, every tile must be flagged and
+    recomputed -- and the result is still the oracle's.  (3) Coordinates beyond the f16 range of the scaled image (|x| >= 60)
+    take the f64 kernel as well."""
+    import ctypes
+
+    from corsair_amd import _lib, backend as B, synth
+
+    monkeypatch.setenv("CS_CHAMFER_STATS", "1")
+    st = (ctypes.c_uint64 * 2)()
+    lib = _lib.load()
+
+    def run(src, tgt, Ts):
+        off_s = [0, len(src)]
+        off_t = [0, len(tgt)]
+        n = len(Ts)
+        return B.chamfer_1dir(torch.from_numpy(src).to(gpu), off_s, torch.from_numpy(tgt).to(gpu), off_t, [0] * n, [0] * n,
+                              torch.from_numpy(Ts).to(gpu)).cpu().numpy()
+
+    # (1) two re-samplings of one shape, voxelised like the bench's clouds, 6 poses near the aligning one
+    full = synth.make_cloud(5, 15000)
+    keep = lambda pc: pc[np.unique(np.floor(pc / 0.03).astype(np.int64), axis=0, return_index=True)[1]]
+    src, tgt = keep(full[:10000]).astype(np.float32), keep(full[5000:]).astype(np.float32)
+    Ts = np.stack([synth.random_pose(40 + i, max_trans=0.02 * i).astype(np.float32) for i in range(6)])
+    Ts[0] = np.eye(4, dtype=np.float32)
+    lib.cs_chamfer_f16_stats(st, 1)
+    got = run(src, tgt, Ts)
+    lib.cs_chamfer_f16_stats(st, 0)
+    tiles, flagged = int(st[0]), int(st[1])
+    monkeypatch.setenv("CS_CHAMFER_F16", "0")
+    ref = run(src, tgt, Ts)
+    monkeypatch.delenv("CS_CHAMFER_F16")
+    assert np.array_equal(got, ref)
+    assert tiles == 6 * -(-len(src) // 256) and flagged <= tiles // 4, (tiles, flagged)
+    want = oracle_native.chamfer_1dir(src, tgt, Ts[3])
+    assert got[3] == pytest.approx(want, rel=1e-12)
+    # (2) four near-copies of every target, shuffled
+    rng = np.random.default_rng(8)
+    base = rng.uniform(-0.8, 0.8, (1200, 3))
+    tgt4 = np.concatenate([base + rng.normal(0, 1e-8, base.shape) for _ in range(4)])
+    tgt4 = tgt4[rng.permutation(len(tgt4))].astype(np.float32)
+    src2 = rng.uniform(-0.8, 0.8, (700, 3)).astype(np.float32)
+    T2 = np.stack([synth.random_pose(7, max_trans=0.1).astype(np.float32)])
+    lib.cs_chamfer_f16_stats(st, 1)
+    got2 = run(src2, tgt4, T2)
+    lib.cs_chamfer_f16_stats(st, 0)
+    assert int(st[0]) == 3 and int(st[1]) == 3            # every tile fell back
+    assert got2[0] == pytest.approx(oracle_native.chamfer_1dir(src2, tgt4, T2[0]), rel=1e-12)
+    # (3) out of the scaled f16 range
+    far = (src2 * 100.0).astype(np.float32)
+    lib.cs_chamfer_f16_stats(st, 1)
+    got3 = run(far, (tgt4[:900] * 100.0).astype(np.float32), np.eye(4, dtype=np.float32)[None])
+    lib.cs_chamfer_f16_stats(st, 0)
+    assert int(st[1]) == int(st[0]) == 3
+    assert got3[0] == pytest.approx(oracle_native.chamfer_1dir(far, (tgt4[:900] * 100.0).astype(np.float32), np.eye(4, dtype=np.float32)), rel=1e-12)
 
 
 def _corr_problem(rng, m, inlier_frac, noise=0.01, pose_id=0):
