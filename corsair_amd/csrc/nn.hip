@@ -547,13 +547,15 @@ __global__ void k_knf_pack_targets(const float* __restrict__ tf, const int64_t* 
 }
 
 // query operand rows: [-2 qh(16) | -2 qh(16) | -2 ql(16)] (scaling by 2 is exact in f16 below the range limit)
-__global__ void k_knf_pack_queries(const float* __restrict__ qf, int64_t n, _Float16* __restrict__ qrows) {
+__global__ void k_knf_pack_queries(const float* __restrict__ qf, int64_t n, _Float16* __restrict__ qrows,
+                                   float* __restrict__ qn32) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   union {
     _Float16 h[48];
     uint4 v[6];
   } row;
+  double n2 = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     _Float16 hi, lo;
@@ -561,12 +563,26 @@ __global__ void k_knf_pack_queries(const float* __restrict__ qf, int64_t n, _Flo
     row.h[c] = hi;
     row.h[16 + c] = hi;
     row.h[32 + c] = lo;
+    n2 = fma((double)qf[i * 16 + c], (double)qf[i * 16 + c], n2);
   }
+  qn32[i] = (float)n2 * 1.0000002f;   // |q|^2, rounded up: error budget of the threshold pass
   uint4* dst = reinterpret_cast<uint4*>(qrows + i * 48);
 #pragma unroll
   for (int c = 0; c < 6; ++c) dst[c] = row.v[c];
 }
 
+// PASS = 1 (round 5): the THRESHOLD pass.  The shortlist kernel is bound by its hits, not by the matrix cores (MFMA busy
+// 0.07): a lane starts with thr = +inf, its running 8th best falls like a record process (~55 hits per lane, and with 64
+// lanes a hit in SOME lane on 70 % of the value steps), and every hit step pays the pending list and its ranking.  This pass
+// bounds the query's k-th distance BEFORE the shortlist pass from tile minima alone -- no per-value work: one MFMA (hi.hi,
+// 16 of the 48 products) per 32 x 32 tile, eight v_min3 for the tile's minimum of the lane's 16 rows, six v_med3 to keep the
+// lane's six smallest tile minima.  The k-th smallest b_k is attained by k DIFFERENT rows, so the exact k-th distance is
+// <= b_k + eps1 and every true neighbour has a full approximate value <= b_k + eps1 + eps3 =: thr0 -- the shortlist pass then
+// starts from thr0 instead of +inf and sees ~8 hits per lane.  eps1 = 2^-9 (|q|^2 + |t|^2max) covers the hi.hi-only value
+// (2 x 2^-11 relative on either side of q.t, times the factor 2, charged twice), eps3 = 2^-15 (...) the three-MFMA value as in
+// k_knn_rescore_f16.  Nothing here decides a result: the shortlist is verified against its final threshold as before and a
+// query whose list is short or unverifiable is recomputed exhaustively.
+template <int PASS>
 __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ work,
                                                  const _Float16* __restrict__ qrows,
                                                  const _Float16* __restrict__ img,
@@ -575,7 +591,10 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
                                                  const int32_t* __restrict__ qlabel,
                                                  const int32_t* __restrict__ perm,
                                                  const int32_t* __restrict__ lab_start,
-                                                 int32_t* __restrict__ cand_i, float* __restrict__ cand_tau) {
+                                                 int32_t* __restrict__ cand_i, float* __restrict__ cand_tau,
+                                                 // PASS 1 writes thr0, PASS 0 starts from it (nullptr: from +inf)
+                                                 float* __restrict__ thr0, const float* __restrict__ qn32,
+                                                 const unsigned* __restrict__ seg_t2max_bits, int kq) {
   constexpr int STAGE_BYTES = KNF_ROWS * KNF_PITCH * 2;  // 21504
   constexpr int STAGE_KIB = STAGE_BYTES / 1024;
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
@@ -629,10 +648,17 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
   float bd[KNF_NG][KNF_KK], pd[KNF_NG][KNF_PEND], thr[KNF_NG];
   int32_t bi[KNF_NG][KNF_KK], pi[KNF_NG][KNF_PEND];
   int pn[KNF_NG];
+  float tb[KNF_NG][6];   // PASS 1: the lane's six smallest tile minima, ascending
 #pragma unroll
   for (int g = 0; g < KNF_NG; ++g) {
     pn[g] = 0;
     thr[g] = INFINITY;
+    if (PASS == 0 && thr0) {
+      const int qloc = wave * 32 * KNF_NG + 32 * g + col;
+      thr[g] = thr0[wk.o0 + (qvalid[g] ? qloc : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tb[g][j] = INFINITY;
 #pragma unroll
     for (int j = 0; j < KNF_KK; ++j) {
       bd[g][j] = INFINITY;
@@ -671,7 +697,7 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
     // the query's KNF_KK-th best
     float t = bd[g][KNF_KK - 1];
     t = fminf(t, __shfl_xor(t, 32));
-    thr[g] = t;
+    thr[g] = fminf(thr[g], t);   // (never above the threshold pass's bound while the lists are still filling)
   };
   const char* gimg = reinterpret_cast<const char*>(img + (int64_t)wk.t0 * KNF_PITCH) + lane * 16;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
@@ -738,6 +764,26 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
 #pragma unroll
         for (int g = 0; g < KNF_NG; ++g) {
           f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bop[g][0], c16, 0, 0, 0);
+          if (PASS == 1) {
+            float m = fminf(fminf(d[0], d[1]), d[2]);
+            m = fminf(fminf(m, d[3]), d[4]);
+            m = fminf(fminf(m, d[5]), d[6]);
+            m = fminf(fminf(m, d[7]), d[8]);
+            m = fminf(fminf(m, d[9]), d[10]);
+            m = fminf(fminf(m, d[11]), d[12]);
+            m = fminf(fminf(m, d[13]), d[14]);
+            m = fminf(m, d[15]);
+            if (use_labels && want[g] != lab) m = INFINITY;
+            // sorted insertion without a branch: new j-th = median of (old j-1-th, old j-th, m)
+            const float o0 = tb[g][0], o1 = tb[g][1], o2 = tb[g][2], o3 = tb[g][3], o4 = tb[g][4], o5 = tb[g][5];
+            tb[g][0] = fminf(o0, m);
+            tb[g][1] = __builtin_amdgcn_fmed3f(o0, o1, m);
+            tb[g][2] = __builtin_amdgcn_fmed3f(o1, o2, m);
+            tb[g][3] = __builtin_amdgcn_fmed3f(o2, o3, m);
+            tb[g][4] = __builtin_amdgcn_fmed3f(o3, o4, m);
+            tb[g][5] = __builtin_amdgcn_fmed3f(o4, o5, m);
+            continue;
+          }
           d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bop[g][1], d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bop[g][2], d, 0, 0, 0);
 #pragma unroll
@@ -771,6 +817,23 @@ __global__ __launch_bounds__(256) void k_knn_f16(const KnnWork* __restrict__ wor
       if (more) store_rows(buf ^ 1, base + KNF_ROWS, tn_next);
       buf ^= 1;
     }
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int g = 0; g < KNF_NG; ++g) {
+      float bk = INFINITY;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j == kq - 1) bk = tb[g][j];
+      bk = fminf(bk, __shfl_xor(bk, 32));     // either lane's k-th smallest tile minimum bounds the query's k-th value
+      const int qloc = wave * 32 * KNF_NG + 32 * g + col;
+      if (qvalid[g] && half == 0) {
+        const float budget = qn32[wk.q0 + qloc] + __uint_as_float(seg_t2max_bits[wk.pad]);
+        // (+ eps1 + eps3, rounded up, and strictly above every value it has to admit)
+        thr0[wk.o0 + qloc] = bk + budget * (0x1.0p-9f + 0x1.0p-14f) + fabsf(bk) * 0x1.0p-20f;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int g = 0; g < KNF_NG; ++g) {
@@ -1971,6 +2034,11 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
     PoolBuf<int32_t> ti32((size_t)(nt_rows ? nt_rows : 1)), cand((size_t)(out_row ? out_row : 1) * 2 * KNF_KK);
     PoolBuf<int32_t> qflag((size_t)(out_row ? out_row : 1)), tile_flag(work.size());
     PoolBuf<unsigned> t2max((size_t)ntseg);
+    // threshold pass (k_knn_f16<1>): per query an upper bound of its k-th distance before the shortlist pass starts
+    // (CS_KNN_TWOPASS=0: the shortlist pass alone, from +inf)
+    const bool two_pass = k <= 6 && !(getenv("CS_KNN_TWOPASS") && getenv("CS_KNN_TWOPASS")[0] == '0');
+    PoolBuf<float> thr0((size_t)(out_row ? out_row : 1)), qn32((size_t)(nq_rows ? nq_rows : 1));
+    CS_REQUIRE(thr0.p && qn32.p, CS_ERR_HIP, "cs_knn_feat: scratch allocation failed");
     PoolBuf<int32_t> torder, rows_in, lab_start;
     PoolBuf<uint32_t> keys, keys_sorted;
     PoolBuf<int64_t> dtoff;
@@ -2006,12 +2074,16 @@ int cs_knn_feat(const float* d_qf, const int64_t* h_qoff, const float* d_tf,
                          (d_tlabel && nt_rows) ? torder.p : (const int32_t*)nullptr, img.p, tn32.p, ti32.p, t2max.p);
     if (nq_rows)
       hipLaunchKernelGGL(k_knf_pack_queries, dim3((unsigned)ceil_div(nq_rows, 256)), dim3(256), 0, s, d_qf,
-                         nq_rows, qrows.p);
+                         nq_rows, qrows.p, qn32.p);
     {
       ProfScope prof("knn", s, knn_flop);
-      hipLaunchKernelGGL(k_knn_f16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, qrows.p, img.p,
-                         tn32.p, ti32.p, d_qlabel, d_perm, (d_tlabel && nt_rows) ? lab_start.p : (const int32_t*)nullptr,
-                         cand.p, tau.p);
+      const int32_t* labs = (d_tlabel && nt_rows) ? lab_start.p : (const int32_t*)nullptr;
+      if (two_pass)
+        hipLaunchKernelGGL(k_knn_f16<1>, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, qrows.p, img.p, tn32.p, ti32.p,
+                           d_qlabel, d_perm, labs, cand.p, tau.p, thr0.p, qn32.p, t2max.p, k);
+      hipLaunchKernelGGL(k_knn_f16<0>, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, qrows.p, img.p,
+                         tn32.p, ti32.p, d_qlabel, d_perm, labs, cand.p, tau.p, two_pass ? thr0.p : (float*)nullptr, qn32.p,
+                         t2max.p, k);
       hipLaunchKernelGGL(k_knn_rescore_f16, dim3((unsigned)work.size()), dim3(256), 0, s, dwork.p, d_qf, d_tf,
                          cand.p, tau.p, t2max.p, k, d_idx, d_dist, qflag.p, tile_flag.p);
       // exhaustive recomputation of the queries whose shortlist could not be verified (normally none)
