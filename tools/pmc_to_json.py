@@ -18,7 +18,7 @@ workload = "chair"
 if "--workload" in sys.argv:
     workload = sys.argv[sys.argv.index("--workload") + 1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WIDE = ("k_ransac_prefilter", "k_knn_f16", "k_topk_f16", "k_conv_mfma", "k_conv_dma")
+WIDE = ("k_ransac_prefilter", "k_knn_f16", "k_topk_f16", "k_conv_mfma", "k_conv_dma", "k_chamfer_f16")
 DOMINANT = {"chair": "k_ransac_prefilter", "table": "k_ransac_prefilter", "stress": "k_conv_dma"}[workload]
 # the FIRST-stage prefilter instantiation (<1, true> by default); the second stage launches <2, false> on a few survivors
 DOM_MATCH = {"k_ransac_prefilter": ("k_ransac_prefilterILi1", "k_ransac_prefilter<1")}.get(DOMINANT, (DOMINANT,))
@@ -31,7 +31,7 @@ FAMILY = {
               "k_segments", "k_fill_table"),
              ("k_pyr_insert", "k_order_finish")),
     "knn": (("k_knn_f16", "k_knn_rescore_f16", "k_knf_pack", "k_knn_feat"), ("k_knf_pack_queries",)),
-    "chamfer": (("k_chamfer",), ("k_chamfer_mfma", "k_chamfer<")),
+    "chamfer": (("k_chamfer",), ("k_chamfer_finish",)),
     "topk": (("k_topk", "k_tkf", "k_dist_matrix", "k_row_topk"), ("k_topk_finish",)),
     "ransac_pre": (("k_ransac_prefilterILi1", "k_ransac_prefilter<1"), ("k_ransac_prefilterILi1", "k_ransac_prefilter<1")),
     "ransac_hyp": (("k_ransac_hyp<", "k_ransac_hypILi"), ("k_ransac_hyp<", "k_ransac_hypILi")),
