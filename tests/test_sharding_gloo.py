@@ -179,6 +179,7 @@ def test_balanced_catalog_all_gather_world2(tmp_path):
 
 def _exact_topk(q, x, k):
     """Reference local top-k: exact f64 squared distances (the oracle's fma chain), ties -> smaller index."""
+    os.environ.setdefault("ORACLE_THREADS", "1")   # (several ranks x one OpenMP team per visible core would spin against each other)
     from oracle import native
 
     d2 = native.dist2_matrix(q.numpy(), x.numpy())
