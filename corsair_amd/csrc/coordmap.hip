@@ -279,44 +279,14 @@ __global__ void k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_ou
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
 }
 
-// The same probes for the samples the LDS kernel flagged (too many voxels / too wide), launched behind
-// it without a host decision: grid (slices, samples), a workgroup of an unflagged sample leaves at once.
-__global__ __launch_bounds__(256) void k_build_nbr_flagged(
-    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int step, int sign,
-    const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, uint64_t mask,
-    int32_t* __restrict__ nbr, unsigned long long* pair_count, const int* __restrict__ flagged) {
-  const int b = blockIdx.y;
-  if (!flagged[b]) return;
-  const int64_t t0 = (int64_t)out_seg[b] * 27, t1 = (int64_t)out_seg[b + 1] * 27;
-  for (int64_t base = t0 + (int64_t)blockIdx.x * 256; base < t1; base += (int64_t)gridDim.x * 256) {
-    const int64_t t = base + threadIdx.x;
-    int found = 0;
-    if (t < t1) {
-      const int64_t o = t / 27;
-      const int k = (int)(t - o * 27);
-      const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
-      const int bb = out_coords[4 * o + 0];
-      const int x = out_coords[4 * o + 1] + sign * dx * step;
-      const int y = out_coords[4 * o + 2] + sign * dy * step;
-      const int z = out_coords[4 * o + 3] + sign * dz * step;
-      int32_t v = -1;
-      if (coord_in_range(bb, x, y, z)) v = hash_lookup(keys, vals, mask, pack_key(bb, x, y, z));
-      nbr[t] = v;
-      found = v >= 0;
-    }
-    const unsigned long long m = __ballot(found);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Kernel maps built in LDS.  Coordinates of a batch are grouped by sample (collate order), and a
-// kernel-map probe never leaves its sample, so one workgroup loads the in-map coordinates of ONE
-// sample into an LDS hash table (30-bit keys relative to the sample's bounding box, 16-bit local row)
-// and answers all 27 probes of its slice of output rows from LDS -- no random global access at all.
-// Samples with more than LDS_MAX_ROWS voxels or bounding boxes wider than 1023 cells are flagged and
-// handled by the global-table kernel (k_build_nbr, restricted to the flagged samples); batches that
-// are not grouped by sample use the global kernel for everything.
+// Kernel maps built in LDS (k_level_maps, below).  Coordinates of a batch are grouped by sample (collate order), and a
+// kernel-map probe never leaves its sample, so one workgroup loads the in-map coordinates of ONE sample into an LDS hash
+// table (30-bit keys relative to the sample's bounding box, 16-bit local row) and answers the probes of its slice of output
+// rows from LDS -- no random global access at all.  Samples with more rows than the table holds or bounding boxes wider
+// than 1023 cells are probed in the level's global table by the same workgroup; batches that are not grouped by sample use
+// the global kernel (k_build_nbr) for everything.  (The per-map kernels of rounds 1-4, k_build_nbr_lds / _flagged, were
+// removed in round 5 after the A/B against k_level_maps: profiles/r5d_kmap_fused_ab.txt, HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
 constexpr int LDS_SLOTS_MAX = 24576;  // 4-B keys + 2-B local rows = 144 KB of the CU's 160 KB LDS (load factor <= 0.625)
 constexpr uint32_t LDS_EMPTY = 0xffffffffu;
@@ -339,140 +309,6 @@ __global__ void k_segments(const int32_t* __restrict__ coords, int64_t n, int n_
 __global__ void k_segment_max(const int32_t* __restrict__ seg, int n_batch, int* __restrict__ flags) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < n_batch) atomicMax(&flags[1], seg[b + 1] - seg[b]);
-}
-
-// grid: x = slice of the sample's output rows, y = sample.  block = NT threads.
-// SLOTS = table size: 24576 (144 KB, one workgroup per CU: the stride-1 maps of 15 k-voxel samples), 8192
-// (48 KB, three per CU) or 2048 (12 KB) for the coarser levels, picked on the host from the mean sample size;
-// a sample that does not fit its table is flagged and goes through the global table like any other overflow.
-// ushift: log2(unit) when the in-map's tensor stride is a power of two (1, 2, 4, 8: every level of the ResUNet),
-// else -1.  The probe loop divides by `unit` six times per probe; as run-time integer divisions (~35 VALU
-// instructions each) they WERE the kernel: 174 -> see DESIGN 7c us per stride-1 map of the stress batch.
-// SYM (in map == out map, a submanifold convolution): row o has row i at offset k exactly when row i has row o at the
-// opposite offset 26 - k, and offset 13 is the row itself.  Only offsets 0..12 are probed; a hit writes both entries
-// (every entry has one writer), misses keep the -1 the table was filled with before the launch.
-template <int SLOTS, int NT, bool SYM>
-__global__ __launch_bounds__(NT) void k_build_nbr_lds(
-    const int32_t* __restrict__ in_coords, const int32_t* __restrict__ in_seg,
-    const int32_t* __restrict__ out_coords, const int32_t* __restrict__ out_seg, int unit, int ushift, int step,
-    int sign, int32_t* __restrict__ nbr, unsigned long long* __restrict__ pair_count,
-    int* __restrict__ fallback) {
-  auto udiv = [&](int v) { return ushift >= 0 ? v >> ushift : v / unit; };          // v >= 0
-  auto umult = [&](int v) { return ushift >= 0 ? (v & (unit - 1)) == 0 : v % unit == 0; };
-  constexpr int LDS_SLOTS = SLOTS;
-  constexpr int LDS_MAX_ROWS = SLOTS / 8 * 5;   // load factor <= 0.625
-  __shared__ uint32_t keys[LDS_SLOTS];
-  __shared__ uint16_t vals[LDS_SLOTS];
-  __shared__ int bmin[3], bmax[3];
-  const int b = blockIdx.y;
-  const int i0 = in_seg[b], i1 = in_seg[b + 1];
-  const int o0 = out_seg[b], o1 = out_seg[b + 1];
-  const int tid = threadIdx.x;
-  if (o1 <= o0) return;
-  const int per = (o1 - o0 + gridDim.x - 1) / gridDim.x;
-  const int s0 = o0 + blockIdx.x * per, s1 = min(o1, s0 + per);
-  if (s0 >= s1) return;
-  if (tid < 3) {
-    bmin[tid] = 0x7fffffff;
-    bmax[tid] = -0x7fffffff;
-  }
-  for (int i = tid; i < LDS_SLOTS; i += NT) keys[i] = LDS_EMPTY;
-  __syncthreads();
-  {
-    // bounding box: per-thread, then per-wave (shuffles), then one LDS atomic per wave and axis
-    // (one atomic per coordinate serialises ~27 k updates on six addresses: 85 us -> measured below)
-    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
-    for (int i = i0 + tid; i < i1; i += NT) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int v = in_coords[4 * i + 1 + a];
-        lo[a] = min(lo[a], v);
-        hi[a] = max(hi[a], v);
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        lo[a] = min(lo[a], __shfl_xor(lo[a], off));
-        hi[a] = max(hi[a], __shfl_xor(hi[a], off));
-      }
-      if ((tid & 63) == 0) {
-        atomicMin(&bmin[a], lo[a]);
-        atomicMax(&bmax[a], hi[a]);
-      }
-    }
-  }
-  __syncthreads();
-  const int mx = bmin[0], my = bmin[1], mz = bmin[2];
-  const int ex = i1 > i0 ? udiv(bmax[0] - mx) : 0, ey = i1 > i0 ? udiv(bmax[1] - my) : 0,
-            ez = i1 > i0 ? udiv(bmax[2] - mz) : 0;
-  if (ex > 1023 || ey > 1023 || ez > 1023 || i1 - i0 > LDS_MAX_ROWS) {
-    if (tid == 0) fallback[b] = 1;
-    return;
-  }
-  for (int i = i0 + tid; i < i1; i += NT) {
-    const uint32_t key = (uint32_t)udiv(in_coords[4 * i + 1] - mx) |
-                         ((uint32_t)udiv(in_coords[4 * i + 2] - my) << 10) |
-                         ((uint32_t)udiv(in_coords[4 * i + 3] - mz) << 20);
-    uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
-    while (true) {
-      const uint32_t old = atomicCAS(&keys[slot], LDS_EMPTY, key);
-      if (old == LDS_EMPTY || old == key) {
-        vals[slot] = (uint16_t)(i - i0);  // coordinates are unique inside a map
-        break;
-      }
-      slot = slot + 1 == LDS_SLOTS ? 0 : slot + 1;
-    }
-  }
-  __syncthreads();
-  int found_total = 0;
-  constexpr int KP = SYM ? 14 : 27;   // offsets handled per row
-  const int total = (s1 - s0) * KP;
-  for (int t = tid; t < total; t += NT) {
-    const int o = s0 + t / KP;
-    const int k = t - (t / KP) * KP;
-    if (SYM && k == 13) {
-      nbr[(int64_t)o * 27 + 13] = o;
-      found_total += 1;
-      continue;
-    }
-    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
-    const int x = out_coords[4 * o + 1] + sign * dx * step - mx;
-    const int y = out_coords[4 * o + 2] + sign * dy * step - my;
-    const int z = out_coords[4 * o + 3] + sign * dz * step - mz;
-    int32_t v = -1;
-    if (x >= 0 && y >= 0 && z >= 0 && umult(x) && umult(y) && umult(z)) {
-      const int cx = udiv(x), cy = udiv(y), cz = udiv(z);
-      if (cx <= ex && cy <= ey && cz <= ez) {
-        const uint32_t key = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
-        uint32_t slot = ((key * 2654435761u) >> 8) % LDS_SLOTS;
-        while (true) {
-          const uint32_t kk = keys[slot];
-          if (kk == key) {
-            v = i0 + (int32_t)vals[slot];
-            break;
-          }
-          if (kk == LDS_EMPTY) break;
-          slot = slot + 1 == LDS_SLOTS ? 0 : slot + 1;
-        }
-      }
-    }
-    if (SYM) {
-      if (v >= 0) {
-        nbr[(int64_t)o * 27 + k] = v;
-        nbr[(int64_t)v * 27 + (26 - k)] = o;
-        found_total += 2;
-      }
-    } else {
-      nbr[(int64_t)o * 27 + k] = v;
-      found_total += v >= 0;
-    }
-  }
-  // block-level pair count: wave reduce, one atomic per wave
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) found_total += __shfl_xor(found_total, off);
-  if ((tid & 63) == 0 && found_total) atomicAdd(pair_count, (unsigned long long)found_total);
 }
 
 // Per-sample segment tables of coordinate maps (computed once, cached on the map): for several maps at once --
@@ -1410,49 +1246,11 @@ static int launch_level(const cs_coordmap* in, const MapPlan* plans, const int* 
   return CS_OK;
 }
 
-// one map through the GLOBAL table (kvol 1, rows not grouped by sample, CS_KMAP_GLOBAL) -- or, CS_KMAP_FUSED=0, through
-// the round-4 per-map LDS kernels (kept for the A/B against k_level_maps)
-static int launch_single(const MapPlan& p, bool legacy_lds, hipStream_t s) {
+// one map through the GLOBAL table (1x1 "maps", rows not grouped by sample, CS_KMAP_GLOBAL)
+static int launch_single(const MapPlan& p, hipStream_t s) {
   cs_kernelmap* km = p.km;
   const int64_t total = km->n_out * km->kvol;
   if (total == 0) return CS_OK;
-  cs_coordmap* in_m = const_cast<cs_coordmap*>(p.in);
-  cs_coordmap* out_m = const_cast<cs_coordmap*>(p.out);
-  if (legacy_lds && km->kvol == 27 && in_m->seg_state == 1 && out_m->seg_state == 1 && in_m->n_batch == out_m->n_batch) {
-    const int nb = in_m->n_batch;
-    PoolBuf<int> fb(nb);
-    CS_REQUIRE(fb.p, CS_ERR_HIP, "cs_kernelmap_build: allocation failed");
-    CS_HIP_CHECK(hipMemsetAsync(fb.p, 0, sizeof(int) * nb, s));
-    static const int slice_wgs = getenv("CS_KMAP_WGS") ? std::max(atoi(getenv("CS_KMAP_WGS")), 1) : 256;
-    int slices = std::min(std::max(slice_wgs / (nb > 0 ? nb : 1), 1), 8);
-    const int64_t need = (p.in->n / (nb > 0 ? nb : 1)) * 5 / 2;
-    const char* env_sym = getenv("CS_KMAP_SYM");
-    const bool sym = p.in == p.out && !km->transposed && (env_sym ? env_sym[0] == '1' : km->n_out >= 200000);
-    if (sym) CS_HIP_CHECK(hipMemsetAsync(km->d_nbr, 0xff, (size_t)total * sizeof(int32_t), s));
-    const int ushift = ushift_of(p.in->tensor_stride);
-#define CS_NBR_LDS(SLOTS_, NT_)                                                                                          \
-  do {                                                                                                                    \
-    if (sym)                                                                                                              \
-      hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, true>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,      \
-                         p.in->d_coords, in_m->d_seg, p.out->d_coords, out_m->d_seg, p.in->tensor_stride, ushift, p.step, \
-                         p.sign, km->d_nbr, p.d_cnt, fb.p);                                                               \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((k_build_nbr_lds<SLOTS_, NT_, false>), dim3((unsigned)slices, (unsigned)nb), dim3(NT_), 0, s,     \
-                         p.in->d_coords, in_m->d_seg, p.out->d_coords, out_m->d_seg, p.in->tensor_stride, ushift, p.step, \
-                         p.sign, km->d_nbr, p.d_cnt, fb.p);                                                               \
-  } while (0)
-    if (need <= 2048 / 8 * 5)
-      CS_NBR_LDS(2048, 256);
-    else if (need <= 8192 / 8 * 5)
-      CS_NBR_LDS(8192, 512);
-    else
-      CS_NBR_LDS(LDS_SLOTS_MAX, 1024);
-#undef CS_NBR_LDS
-    hipLaunchKernelGGL(k_build_nbr_flagged, dim3(64, (unsigned)nb), dim3(256), 0, s, p.out->d_coords, out_m->d_seg, p.step,
-                       p.sign, p.in->d_keys, p.in->d_vals, p.in->capacity - 1, km->d_nbr, p.d_cnt, fb.p);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
-  }
   hipLaunchKernelGGL(k_build_nbr, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, p.out->d_coords, km->n_out, km->kvol,
                      p.step, p.sign, p.in->d_keys, p.in->d_vals, p.in->capacity - 1, km->d_nbr, p.d_cnt, (const int*)nullptr);
   CS_LAUNCH_CHECK();
@@ -1521,8 +1319,8 @@ extern "C" {
 // per level serves every map of the group from one LDS table per sample, and the levels run on up to four streams (the
 // caller's and the thread's side streams: every side stream starts behind the caller's stream and the caller's stream
 // continues behind all of them; scratch freed meanwhile is handed back to the pool only after that join).  Then ONE radix
-// sort gives every map its tiling order.  CS_KMAP_STREAMS=1: everything on the caller's stream; CS_KMAP_FUSED=0: the
-// round-4 per-map kernels; CS_KMAP_GLOBAL=1: the global-table kernel for everything.
+// sort gives every map its tiling order.  CS_KMAP_STREAMS=1: everything on the caller's stream; CS_KMAP_GLOBAL=1: the
+// global-table kernel for everything.
 int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordmap* const* out, const int* kernel_size,
                             const int* transposed, void* stream, cs_kernelmap** km_out) {
   CS_REQUIRE(n >= 0 && (n == 0 || (in && out && kernel_size && transposed && km_out)), CS_ERR_INVALID,
@@ -1539,7 +1337,6 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
     plans[i].out = out[i];
   }
   const bool global_only = getenv("CS_KMAP_GLOBAL") != nullptr;
-  static const bool fused_on = !(getenv("CS_KMAP_FUSED") && getenv("CS_KMAP_FUSED")[0] == '0');
   // per-sample segments of the coordinate maps (lazily, cached on the map): on the caller's stream before the streams fork
   if (!global_only) {
     std::vector<cs_coordmap*> need;
@@ -1606,7 +1403,7 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
     cs_coordmap* in_m = const_cast<cs_coordmap*>(in[i]);
     cs_coordmap* out_m = const_cast<cs_coordmap*>(out[i]);
     p.ordered = km->kvol == 27;
-    p.fused = fused_on && !global_only && km->kvol == 27 && in_m->seg_state == 1 && out_m->seg_state == 1 &&
+    p.fused = !global_only && km->kvol == 27 && in_m->seg_state == 1 && out_m->seg_state == 1 &&
               in_m->n_batch == out_m->n_batch;
     if (p.ordered) {
       p.base = total_rows;
@@ -1661,7 +1458,7 @@ int cs_kernelmap_build_many(int n, const cs_coordmap* const* in, const cs_coordm
     }
     for (int i = 0; i < n && rc == CS_OK; ++i) {
       if (done[i]) continue;
-      rc = launch_single(plans[i], !fused_on && !global_only, st[lane++ % ns]);
+      rc = launch_single(plans[i], st[lane++ % ns]);
     }
     // join (also on the error path: the side streams may hold work that reads scratch of this call)
     for (int k = 1; k < ns; ++k) {

@@ -111,9 +111,10 @@ def test_resunet_forward_bit_exact(gpu, oracle_native):
     assert np.array_equal(g.cpu().numpy(), want_g)
 
 
-def test_kernel_maps_symmetric_probes_at_size(gpu, monkeypatch):
-    """A map large enough for the library to pick the symmetric build on its own (>= 200 000 rows) equals the map built
-    with every offset probed, entry for entry, and a forward over both gives the same features."""
+def test_kernel_maps_of_a_large_batch_equal_the_global_table_build(gpu, monkeypatch):
+    """A stress-sized stride-1 level (>= 200 000 rows, 24 clouds at 2 cm; the 144-KB LDS table configuration): the map the
+    level kernel builds from its per-sample LDS tables equals the map probed in the global hash table (CS_KMAP_GLOBAL=1),
+    entry for entry; a submanifold map has every row as its own centre neighbour."""
     from corsair_amd import backend as B, synth
 
     clouds = [synth.make_cloud(c, 15000) for c in range(24)]
@@ -122,13 +123,13 @@ def test_kernel_maps_symmetric_probes_at_size(gpu, monkeypatch):
     _, grid, _ = B.voxelize(xyz, off, 0.02)
     c1 = B.CoordMap.create(grid, 1)
     assert c1.n >= 200000
-    monkeypatch.setenv("CS_KMAP_SYM", "0")
-    full = B.KernelMap.build(c1, c1)
-    monkeypatch.delenv("CS_KMAP_SYM")
-    sym = B.KernelMap.build(c1, c1)
-    assert sym.num_pairs == full.num_pairs
-    assert torch.equal(sym.table(), full.table())
-    t = full.table()
+    lds = B.KernelMap.build(c1, c1)
+    monkeypatch.setenv("CS_KMAP_GLOBAL", "1")
+    glob = B.KernelMap.build(c1, c1)
+    monkeypatch.delenv("CS_KMAP_GLOBAL")
+    assert lds.num_pairs == glob.num_pairs
+    assert torch.equal(lds.table(), glob.table())
+    t = lds.table()
     assert bool((t[:, 13] == torch.arange(c1.n, device=gpu, dtype=torch.int32)).all())
 
 
@@ -157,16 +158,12 @@ def test_kernel_maps_build_many_equals_single_builds(gpu):
     assert B.KernelMap.build_many([]) == []
 
 
-@pytest.mark.parametrize("sym", [None, "1", "0"])
-def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, sym):
+@pytest.mark.parametrize("hint", [0, 5])
+def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, hint):
     """LDS-built kernel maps: a batch mixing an ordinary sample, one too large for the LDS table
     (> 15 360 voxels), one with a bounding box wider than 1023 cells and an empty batch index; the
-    flagged samples go through the global-table kernel.  Also: rows not grouped by sample.
-    sym = "1": the submanifold maps (s1, s2, s4, s8) are built from half of the probes, a hit writing both mirrored
-    entries (the library does that by itself only for maps of >= 200 000 rows: see
-    test_kernel_maps_symmetric_probes_at_size)."""
-    if sym is not None:
-        monkeypatch.setenv("CS_KMAP_SYM", sym)
+    workgroups of the samples that do not fit probe the level's global table instead.  Also: rows not grouped by
+    sample (the global kernel for the whole map).  hint: batch size announced to the coordinate pyramid or not."""
     from oracle import resunet as oref
     from oracle import sparse as osp
 
@@ -181,7 +178,9 @@ def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, sym):
              np.zeros((0, 3), np.int64), cloud(500, 6)]
     assert len(parts[1]) > 15360
     coords = np.concatenate([np.concatenate([np.full((len(p), 1), b), p], 1) for b, p in enumerate(parts)]).astype(np.int32)
-    m = _maps(gpu, coords)
+    from corsair_amd import engine
+
+    m = engine.BatchMaps(torch.from_numpy(coords).to(gpu), hint)
     omaps, okm = oref.build_maps(coords)
     for name, nbr in okm.items():
         km = getattr(m, name)
@@ -190,7 +189,7 @@ def test_kernel_maps_lds_path_with_fallback_samples(gpu, monkeypatch, sym):
     # interleaved batch indices (not grouped): whole map falls back to the global table
     perm = rng.permutation(len(coords))
     shuffled = coords[perm]
-    m2 = _maps(gpu, shuffled)
+    m2 = engine.BatchMaps(torch.from_numpy(shuffled).to(gpu), hint)
     _, okm2 = oref.build_maps(shuffled)
     for name in ("s1", "s1_s2", "s2_s1_T"):
         assert np.array_equal(getattr(m2, name).table().cpu().numpy(), okm2[name]), name

@@ -1,6 +1,6 @@
 """Time the kernel-map construction of one batch (coordinate maps of strides 1/2/4/8 + the ten kernel maps with their
 tiling order) and one forward of the network on it.  usage: kmap_bench.py [stress|chair] [reps]
-Env switches are read by the library: CS_KMAP_FUSED=0 (round-4 per-map kernels), CS_KMAP_TRACE=1 (phase report)."""
+Env switches are read by the library: CS_PYRAMID=0 (chained level calls), CS_KMAP_GLOBAL=1 (global-table probes), CS_KMAP_TRACE=1 (phase report)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
