@@ -1821,25 +1821,15 @@ __global__ __launch_bounds__(256) void k_chamfer_f16(const ChamferWork* __restri
         m = fminf(fminf(m, d[11]), d[12]);
         m = fminf(fminf(m, d[13]), d[14]);
         m = fminf(m, d[15]);
-        const bool hit = m < b3[g];
-        if (__any(hit)) {
-          if (hit) {
-            if (m < b2[g]) {
-              b3[g] = b2[g];
-              if (m < b1[g]) {
-                b2[g] = b1[g];
-                t2[g] = t1[g];
-                b1[g] = m;
-                t1[g] = tile;
-              } else {
-                b2[g] = m;
-                t2[g] = tile;
-              }
-            } else {
-              b3[g] = m;
-            }
-          }
-        }
+        // sorted insertion of the tile minimum without a branch: new j-th value = median of (old j-1-th, old j-th, m);
+        // the tile ids follow the two comparisons
+        const float o1 = b1[g], o2 = b2[g];
+        const bool lt1 = m < o1, lt2 = m < o2;
+        b1[g] = fminf(o1, m);
+        b2[g] = __builtin_amdgcn_fmed3f(o1, o2, m);
+        b3[g] = __builtin_amdgcn_fmed3f(o2, b3[g], m);
+        t2[g] = lt1 ? t1[g] : (lt2 ? tile : t2[g]);
+        t1[g] = lt1 ? tile : t1[g];
       }
     }
     if (more) store_stage(buf ^ 1);
