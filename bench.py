@@ -106,6 +106,10 @@ def parse():
     ap.add_argument("--embed-group", type=int, default=4,
                     help="N consecutive steps of the chair / table workload share one forward of the network "
                          "(N x 32 clouds; retrieval and registration stay per step of 32 queries); 1: one forward per step")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="batches in flight in the pass that gives `value` (host threads x HIP streams; default 3); 0: the "
+                         "depth in 3..6 that leaves the K timed steps the least ragged last round (experiment: faster on "
+                         "average, but one run in four shows a 0.5-s stall somewhere -- DESIGN 7)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the extra pass with three batches in flight reported as `batches_in_flight`")
     return ap.parse_args()
@@ -954,7 +958,7 @@ class Runner:
 
         self.ctx, self.wl, self.depth = ctx, wl, depth
         self.group = max(1, int(getattr(ctx.args, "embed_group", 1)))
-        self.streams = [] if ctx.dry else [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, 3))]
+        self.streams = [] if ctx.dry else [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, IN_FLIGHT[0], 6))]
         self.workers = {}
 
     def worker_of(self, w):
@@ -1084,11 +1088,11 @@ def timed_region(ctx, wl, runner, warmup, steps):
 
 
 def piped_pass(ctx, wl, runner, warmup, steps):
-    """The same K steps again with THREE batches in flight (three host threads x three HIP streams), bracketed like the
+    """The same K steps again with several batches in flight (IN_FLIGHT host threads, one HIP stream each), bracketed like the
     timed region (barrier + synchronize on both sides), results compared with the pass before.  Returns (seconds,
     identical).  The library's event profile stays off: launches of different batches share the GPU here."""
     seq_results = {r[0]: r for r in wl.results}
-    runner.run_steps(0, min(3, warmup + steps), depth=3)   # untimed: every worker's first step (cold scratch)
+    runner.run_steps(0, min(IN_FLIGHT[0], warmup + steps), depth=IN_FLIGHT[0])   # untimed: every worker's first step (cold scratch)
     wl.results.clear()
     frozen = os.environ.get("BENCH_GC", "freeze") == "freeze"
     if frozen:
@@ -1097,7 +1101,7 @@ def piped_pass(ctx, wl, runner, warmup, steps):
     try:
         ctx.barrier()
         t2 = time.time()
-        runner.run_steps(warmup, warmup + steps, depth=3)
+        runner.run_steps(warmup, warmup + steps, depth=IN_FLIGHT[0])
         ctx.barrier()
         piped_elapsed = time.time() - t2
     finally:
@@ -1121,6 +1125,20 @@ def overlap_probe_allowed(depth, steps, disabled, world, wl):
 
 
 LEG_STEPS, LEG_WARMUP = 8, 2
+IN_FLIGHT = [3]     # batches in flight of the pass that gives `value` (--in-flight)
+
+
+def auto_in_flight(steps):
+    """Depth of the batches-in-flight pass.  Steps are dealt to the workers round-robin, so K steps at depth d take
+    ceil(K / d) rounds: the depth in 3..6 with the fullest rounds, the larger one on ties.  With eight hardware queues the
+    chair rate still rises from three to five / six batches in flight (1 870 - 1 947 -> 1 987 - 2 016 queries/s) and stress from three to
+    four (9 595 - 9 774 -> 9 950 - 9 994 clouds/s); table is flat (profiles/r5s_in_flight_depth_sweep.txt)."""
+    best, best_eff = 3, 0.0
+    for d in (3, 4, 5, 6):
+        eff = steps / float(d * -(-steps // d))
+        if eff >= best_eff - 1e-12:
+            best, best_eff = d, eff
+    return best
 
 
 def extra_workload_leg(ctx, args, name):
@@ -1146,16 +1164,22 @@ def extra_workload_leg(ctx, args, name):
     elapsed, _, fam = timed_region(lctx, wl, runner, LEG_WARMUP, LEG_STEPS)
     cfg = wl.config(LEG_STEPS)
     units = LEG_STEPS * wl.units_per_step
-    # the same second pass as the headline: the K steps again with three batches in flight, results compared
-    piped_elapsed, same = piped_pass(lctx, wl, runner, LEG_WARMUP, LEG_STEPS)
+    # the same second pass as the headline: the K steps again with several batches in flight, results compared
+    saved_depth = IN_FLIGHT[0]
+    if args.in_flight <= 0:
+        IN_FLIGHT[0] = auto_in_flight(LEG_STEPS)
+    try:
+        piped_elapsed, same = piped_pass(lctx, wl, runner, LEG_WARMUP, LEG_STEPS)
+    finally:
+        leg_depth, IN_FLIGHT[0] = IN_FLIGHT[0], saved_depth
     runner.close()
     piped = bool(same)        # the headline pass is fixed a priori (see main): three in flight whenever the results are identical
     head = piped_elapsed if piped else elapsed
     leg = {"value": units / head, "unit": "queries/s", "steps": LEG_STEPS, "warmup": LEG_WARMUP,
-           "ms_per_step": head / LEG_STEPS * 1e3, "value_pass": "three batches in flight" if piped else "sequential",
+           "ms_per_step": head / LEG_STEPS * 1e3, "value_pass": ("%d batches in flight" % leg_depth) if piped else "sequential",
            "sequential": {"value": units / elapsed, "ms_per_step": elapsed / LEG_STEPS * 1e3},
            "batches_in_flight": {"value": units / piped_elapsed, "ms_per_step": piped_elapsed / LEG_STEPS * 1e3,
-                                 "identical_results": bool(same)},
+                                 "identical_results": bool(same), "depth": leg_depth},
            "units_per_step": wl.units_per_step,
            "config": cfg, "roofline": roofline_of(fam, None, leg_args),
            "kernel_ms": {k: round(v["ms"], 3) for k, v in fam.items()}}
@@ -1242,6 +1266,13 @@ class DryWorkload:
 
 def main():
     args = parse()
+    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (runtime default 4).  A step with three batches in
+    # flight keeps ~12 streams busy (three workers x (caller + RANSAC side streams + kernel-map streams)); with 8 queues fewer
+    # of them serialise behind each other: chair + 4.5 %, table + 5.7 %, stress +- 0 on alternated runs of one box
+    # (profiles/r5q_hw_queues_ab.txt; round 4 measured + 1 - 5 % and a cliff at 16 / 32, which is why it is 8 and not more).
+    # Must be in the environment before the first HIP call; an explicit setting of the caller wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    IN_FLIGHT[0] = max(2, int(args.in_flight)) if args.in_flight > 0 else auto_in_flight(args.steps)
     maybe_self_launch(args)
     # The contract: rank 0 prints ONE JSON line on stdout.  Libraries write there too (torch's gloo backend announces
     # "[Gloo] Rank 0 is connected to ..." on stdout when the control-plane group comes up): from here on file descriptor 1
@@ -1312,7 +1343,7 @@ def main():
     # all-gathers in an order of their own and the ranks' collectives would no longer pair up)
     if overlap_probe_allowed(depth, args.steps, args.no_overlap_probe, ctx.world, wl):
         overlap = piped_pass(ctx, wl, runner, args.warmup, args.steps)
-        ctx.log("three batches in flight: %d steps in %.3fs, identical results: %s" % (args.steps, overlap[0], overlap[1]))
+        ctx.log("%d batches in flight: %d steps in %.3fs, identical results: %s" % (IN_FLIGHT[0], args.steps, overlap[0], overlap[1]))
     # contract: the MAX over ranks of the barrier-to-barrier time; per-rank own times show the balance
     elapsed, ov = ctx.reduce_max([elapsed, overlap[0] if overlap else 0.0])
     if overlap:
@@ -1331,8 +1362,9 @@ def main():
         # THAT pass (in the pipelined one a launch's event time includes its neighbours).
         piped = overlap is not None and bool(overlap[1]) and not args.sequential_value
         head_elapsed = overlap[0] if piped else elapsed
-        cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": 3 if piped else depth,
-                    "value_pass": "three batches in flight" if piped else "sequential"})
+        cfg.update({"parallelism": "dp%d" % ctx.world, "batches_in_flight": IN_FLIGHT[0] if piped else depth,
+                    "value_pass": ("%d batches in flight" % IN_FLIGHT[0]) if piped else "sequential",
+                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")})
         if hasattr(wl, "step_group"):
             cfg["embed_batches_per_forward"] = max(1, args.embed_group)   # both passes
         out = {
@@ -1344,7 +1376,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": head_elapsed / args.steps * 1e3,
-            "value_pass": "three batches in flight" if piped else "sequential",
+            "value_pass": ("%d batches in flight" % IN_FLIGHT[0]) if piped else "sequential",
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -1378,7 +1410,7 @@ def main():
             out["roofline"]["pass"] = "sequential"
         if overlap:
             out["batches_in_flight"] = {
-                "depth": 3, "value": total_units / overlap[0], "unit": "queries/s",
+                "depth": IN_FLIGHT[0], "value": total_units / overlap[0], "unit": "queries/s",
                 "ms_per_step": overlap[0] / args.steps * 1e3, "identical_results": bool(overlap[1]),
                 "is_headline": bool(piped),
                 "note": "the same K batches with three host threads x three HIP streams (the library's scratch cache is per "

@@ -468,6 +468,11 @@ def main(argv=None):
     from .utils import ckpts, pc_dist
 
     a = build_parser().parse_args(argv)
+    # (eight hardware queues for the streams of the registration batches in flight: bench.py's note; only effective when
+    # nothing has touched the GPU yet -- the command-line entry --, an explicit setting wins)
+    import os
+
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     sd, esd = ckpts.load_state_dicts(a.checkpoint)
     if esd is None:
         raise SystemExit("checkpoint has no embedding_state_dict: retrieval needs the descriptor head (evaluation.py:199)")

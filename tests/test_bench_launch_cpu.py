@@ -110,7 +110,7 @@ def test_gpus8_launcher_end_to_end_on_cpu_ranks():
     assert out["n_gpus"] == 8 and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["dist"]["backend"] == "gloo" and len(out["dist"]["rank_elapsed_s"]) == 8
     assert out["config"]["parallelism"] == "dp8" and out["config"]["catalog"] == 11
-    assert out["batches_in_flight"]["identical_results"] is True and out["config"]["value_pass"] == "three batches in flight"
+    assert out["batches_in_flight"]["identical_results"] is True and out["config"]["value_pass"] == "3 batches in flight"
     assert "DRY RUN" in out["metric"] and "not a measurement" in out["config"]["workload"]
     assert "8 ranks on 0 visible device(s)" in p.stderr          # the launcher chose gloo because the ranks share devices
 
@@ -126,5 +126,7 @@ def test_headline_pass_is_fixed_a_priori_not_by_speed():
     leg = {"value": 10.0, "ms_per_step": 1.0, "steps": 8, "value_pass": "three batches in flight",
            "sequential": {"value": 12.0}, "batches_in_flight": {"identical_results": True},
            "roofline": {"kernel": "k", "frac": 0.25, "peak": 1.0, "unit": "TFLOP/s"}, "config": {"workload": "configs[2]: x"}}
+    # depth of the batches-in-flight pass: the fullest rounds in 3..6, the larger depth on ties
+    assert [bench.auto_in_flight(k) for k in (20, 8, 10, 12, 7, 2, 1)] == [5, 4, 5, 6, 4, 3, 3]
     s = bench.leg_summary(leg)
     assert s["value"] == 10.0 and s["sequential_value"] == 12.0 and s["workload"] == "configs[2]" and s["roofline_frac"] == 0.25
