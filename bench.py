@@ -953,13 +953,24 @@ class Runner:
     worker are created on its first step, so a worker that is started for the timed pass only would pay hipMalloc
     and thread start-up inside the timed region."""
 
+    # Worker threads and their streams are shared by every Runner of the process (headline and legs).  The library keeps
+    # per-thread side streams (RANSAC front halves, kernel-map levels) for the life of a thread and HIP maps all streams of
+    # the process onto a handful of hardware queues: a leg that started fresh threads doubled the live streams, its workers'
+    # streams then shared queues, and its batches-in-flight pass fell BELOW its sequential pass (profiles/r5x_*: table leg
+    # 757 - 770 in flight against 820 sequential).
+    _workers = {}
+    _streams = []
+
     def __init__(self, ctx, wl, depth):
         import torch
 
         self.ctx, self.wl, self.depth = ctx, wl, depth
         self.group = max(1, int(getattr(ctx.args, "embed_group", 1)))
-        self.streams = [] if ctx.dry else [torch.cuda.Stream(device=ctx.dev) for _ in range(max(depth, IN_FLIGHT[0], 6))]
-        self.workers = {}
+        if not ctx.dry:
+            while len(Runner._streams) < max(depth, IN_FLIGHT[0], 3):
+                Runner._streams.append(torch.cuda.Stream(device=ctx.dev))
+        self.streams = Runner._streams
+        self.workers = Runner._workers
 
     def worker_of(self, w):
         from concurrent.futures import ThreadPoolExecutor
@@ -1039,9 +1050,7 @@ class Runner:
             f.result()              # surfaces worker failures in the main thread
 
     def close(self):
-        for ex in self.workers.values():
-            ex.shutdown(wait=True)
-        self.workers.clear()
+        """(the shared workers live until the process ends: see above)"""
 
 
 def timed_region(ctx, wl, runner, warmup, steps):
