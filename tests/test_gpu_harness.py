@@ -128,3 +128,27 @@ def test_bench_grouped_forward_equals_one_forward_per_step(gpu, monkeypatch):
         for i in (2, 3, 4, 6):                                  # T_best, T_ransac, Chamfer, iterations
             assert np.array_equal(r[i], s[i]), i
         assert wl.same_results(r, s)
+
+
+def test_bench_converging_leg_recovers_the_poses(gpu, monkeypatch):
+    """bench.py's `converging` leg: the chair shapes with pose-invariant stand-in features -- retrieval
+    finds the CAD every query was sampled from, sym_pose returns its pose (RRE <= 15 deg for all, mean of a few degrees) and the
+    RANSACs leave through the confidence bound instead of running 100 000 iterations."""
+    import sys
+
+    import bench
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--catalog", "40", "--steps", "2", "--warmup", "0"])
+    args = bench.parse()
+    ctx = bench.Ctx(args)
+    wl = bench.RegistrationWorkload(ctx, "chair", converging=True)
+    wl.setup()
+    for b in range(2):
+        wl.step(b)
+    cfg = wl.config(2)
+    assert cfg["top1_hit_rate"] == 1.0
+    assert cfg["rre_15"] >= 0.95 and cfg["rre_mean_deg"] < 5.0
+    assert cfg["ransac_early_exit_share"] > 0.8 and cfg["ransac_mean_iters"] < 30000
+    assert "CONVERGING" in cfg["workload"]
