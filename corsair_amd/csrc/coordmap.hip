@@ -498,6 +498,18 @@ struct OrderTab {
   int n;
   OrderMap m[ORDER_MAX_MAPS];
 };
+// Bit j of a row's tiling mask stands for kernel offset KORDER[j]: the centre, the six face neighbours, the twelve edge
+// neighbours, the eight corner neighbours (by |d|_1, then by k).  The frequent offsets sit in the low bits, the rare corner
+// offsets decide the coarse order of the Gray ranks -- rows that need a rare offset end up in the same 32-row groups.  Against
+// the Gray rank of the mask in plain k order the executed / useful matrix work of the convolutions drops 1.190 -> 1.160 on the
+// 64-cloud stress batch (stride-1 maps 1.31 -> 1.22), 1.270 -> 1.231 on a 24-cloud batch (tools/exec_ratio_cpu.py).
+__device__ const int8_t KORDER[32] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 0, 2, 6, 8, 18, 20, 24, 26, 0, 0, 0, 0, 0};
+__device__ __forceinline__ uint32_t unpermute_mask(uint32_t m) {   // tiling mask (bit j = offset KORDER[j]) -> bit k = offset k
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < 27; ++j) out |= ((m >> j) & 1u) << KORDER[j];
+  return out;
+}
 __device__ __forceinline__ uint32_t gray_rank(uint32_t m) {   // r with r ^ (r >> 1) == m
   m ^= m >> 1;
   m ^= m >> 2;
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256) void k_row_keys_all(const OrderTab tab, uint32
   const int64_t o = (int64_t)(blockIdx.x - mp.kblk0) * 256 + threadIdx.x;
   if (o >= mp.n_out) return;
   uint32_t m = 0;
-  for (int k = 0; k < 27; ++k) m |= (mp.nbr[o * 27 + k] >= 0 ? 1u : 0u) << k;
+  for (int j = 0; j < 27; ++j) m |= (mp.nbr[o * 27 + KORDER[j]] >= 0 ? 1u : 0u) << j;
   key[mp.base + o] = mp.tag | gray_rank(m);
   row[mp.base + o] = (int32_t)o;
 }
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(256) void k_order_finish(const OrderTab tab, const 
         m |= rank ^ (rank >> 1);
       }
     }
-    mp.gmask[e] = m;
+    mp.gmask[e] = unpermute_mask(m);
   }
 }
 
@@ -691,7 +703,8 @@ __global__ __launch_bounds__(NT) void k_level_maps(const LevelArgs a) {
   }
   if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
 
-  const int k = tid & 31;                             // offset of this lane; lanes 27..31 of a row idle
+  const int kj = tid & 31;                            // lane j of a row handles offset KORDER[j]; lanes 27..31 idle
+  const int k = kj < 27 ? (int)KORDER[kj] : 27;       // (the ballot bit of lane j is then bit j of the tiling mask)
   const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
   const int sh = tid & 32;                            // this row's half of the wave ballot
 #pragma unroll 1
@@ -710,7 +723,7 @@ __global__ __launch_bounds__(NT) void k_level_maps(const LevelArgs a) {
     auto emit = [&](int o, int32_t v) {
       if (k < 27) nbr[(int64_t)o * 27 + k] = v;
       const uint32_t m = (uint32_t)(__ballot(v >= 0) >> sh) & 0x7ffffffu;
-      if (k == 0) {
+      if (kj == 0) {
         found += __popc(m);
         if (jkey) {
           jkey[o] = tag | gray_rank(m);

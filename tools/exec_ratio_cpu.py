@@ -32,6 +32,22 @@ def inv_gray(m):
     return r
 
 
+# the tiling key of coordmap.hip (round 5): bit j of the mask = kernel offset KORDER[j] (centre, faces, edges, corners),
+# then the Gray rank; ORDER=k on the command line (4th argument) evaluates the plain-k order of rounds 3-4
+OFFS = [(k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1) for k in range(27)]
+KORDER = sorted(range(27), key=lambda k: (sum(abs(v) for v in OFFS[k]), k))
+PLAIN = len(sys.argv) > 4 and sys.argv[4] == "k"
+
+
+def tiling_key(mask):
+    if PLAIN:
+        return inv_gray(mask)
+    pm = np.zeros_like(mask)
+    for j, k in enumerate(KORDER):
+        pm |= ((mask >> np.uint32(k)) & np.uint32(1)) << np.uint32(j)
+    return inv_gray(pm)
+
+
 tot = {32: 0.0, 16: 0.0, "useful": 0.0}
 print("%-8s %8s %9s | executed / useful at 32-row groups | at 16-row groups | share of the network's useful work" % ("map", "rows", "pairs"))
 rows_out = []
@@ -39,7 +55,7 @@ for name, w in LAYERS.items():
     nbr = okm[name]
     has = nbr >= 0
     mask = (has.astype(np.uint32) << np.arange(27, dtype=np.uint32)).sum(1).astype(np.uint32)
-    m = mask[np.argsort(inv_gray(mask), kind="stable")]
+    m = mask[np.argsort(tiling_key(mask), kind="stable")]
     pairs = int(has.sum())
     ratio = {}
     for G in (32, 16):
