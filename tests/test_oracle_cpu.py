@@ -549,3 +549,20 @@ def test_checkpoint_round_trip(tmp_path):
     assert set(sd) == {"weight", "bias"} and esd is not None
     ckpts.save_checkpoint(model, None, opt, sched, 8, str(tmp_path / "out"), "net_only.pth")
     assert "embedding_state_dict" not in torch.load(str(tmp_path / "out" / "net_only.pth"), weights_only=False)
+
+
+def test_tiling_mask_bit_order_is_centre_faces_edges_corners():
+    """coordmap.hip's KORDER (bit j of a row's tiling mask = kernel offset KORDER[j]): the 27 offsets k = (dx+1) + 3 (dy+1) +
+    9 (dz+1) sorted by |d|_1 (centre, six faces, twelve edges, eight corners), then by k -- a permutation, and the table
+    tools/exec_ratio_cpu.py evaluates is the same one."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "corsair_amd", "csrc", "coordmap.hip")).read()
+    body = re.search(r"KORDER\[32\]\s*=\s*\{([^}]*)\}", src).group(1)
+    table = [int(v) for v in body.split(",")]
+    assert len(table) == 32 and table[27:] == [0] * 5
+    offs = [(k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1) for k in range(27)]
+    want = sorted(range(27), key=lambda k: (sum(abs(v) for v in offs[k]), k))
+    assert table[:27] == want and sorted(want) == list(range(27))
+    assert want[0] == 13 and [sum(abs(v) for v in offs[k]) for k in want] == [0] + [1] * 6 + [2] * 12 + [3] * 8
