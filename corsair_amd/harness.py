@@ -11,6 +11,8 @@ Differences in structure (not in results) from the reference loops:
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -276,6 +278,29 @@ def retrieval_stat(pipe, q_desc, lib_desc, best_match, table):
     return retrieval.scan2cad_retrieval_eval_rank(rank, table, best_match, pos_n)
 
 
+# Worker threads (and one torch stream each per device) of the batches-in-flight mode, kept for the life of the process: the
+# library gives every host thread its own side streams and scratch cache and HIP maps all streams of a process onto a handful
+# of hardware queues, so a fresh set of threads per evaluation (a ThreadPoolExecutor per call, rounds 3-4) kept adding live
+# streams -- repeated evaluations in one process (bench.py --scaling strong) then share queues between workers.
+_WORKERS = {}
+_WORKER_STREAMS = {}
+
+
+def _worker(w):
+    from concurrent.futures import ThreadPoolExecutor
+
+    if w not in _WORKERS:
+        _WORKERS[w] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="corsair-register%d" % w)
+    return _WORKERS[w]
+
+
+def _worker_stream(dev, w):
+    key = (dev.type, dev.index, w)
+    if key not in _WORKER_STREAMS:
+        _WORKER_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _WORKER_STREAMS[key]
+
+
 def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, force_gate=False, batch_size=None,
                      in_flight=1):
     """The registration loop of evaluation.py:297-331 over the embedded queries `qs`, whose GLOBAL query numbers are
@@ -314,23 +339,27 @@ def register_queries(pipe, qs, query_ids, cat, pos_idx, syms, base_T, lib_T, for
     if depth <= 1 or not on_gpu:
         done = [one(loc) for loc in batches]
     else:
-        from concurrent.futures import ThreadPoolExecutor
-
         dev = torch.device(pipe.device)
         torch.cuda.synchronize(dev)          # the embedded sets were made on the caller's stream
-        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         done = [None] * len(batches)
 
         def work(w):
             if dev.index is not None:
                 torch.cuda.set_device(dev.index)
-            with torch.cuda.stream(streams[w]):
+            st = _worker_stream(dev, w)
+            with torch.cuda.stream(st):
                 for i in range(w, len(batches), depth):
                     done[i] = one(batches[i])
-                streams[w].synchronize()
+                st.synchronize()
 
-        with ThreadPoolExecutor(max_workers=depth, thread_name_prefix="corsair-register") as ex:
-            for f in [ex.submit(work, w) for w in range(depth)]:
+        if os.environ.get("CORSAIR_REGISTER_FRESH_THREADS") == "1":     # (A/B: a fresh set of threads per call, as in rounds 3-4)
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=depth, thread_name_prefix="corsair-register") as ex:
+                for f in [ex.submit(work, w) for w in range(depth)]:
+                    f.result()
+        else:
+            for f in [_worker(w).submit(work, w) for w in range(depth)]:
                 f.result()               # surfaces worker failures
     return {k: np.concatenate([np.asarray(d[k]) for d in done]) for k in C_.NAMES}
 
