@@ -1422,7 +1422,7 @@ def main():
                 "depth": IN_FLIGHT[0], "value": total_units / overlap[0], "unit": "queries/s",
                 "ms_per_step": overlap[0] / args.steps * 1e3, "identical_results": bool(overlap[1]),
                 "is_headline": bool(piped),
-                "note": "the same K batches with three host threads x three HIP streams (the library's scratch cache is per "
+                "note": "the same K batches with `depth` host threads, one HIP stream each (the library's scratch cache is per "
                         "thread and stream-ordered); results compared with the sequential pass"}
         if ctx.world == 1 and args.workload == "chair" and not strong and not args.no_extra_workloads:
             # configs[2] and configs[4] under the same clock as the headline (short legs, same measurement).  BEFORE the
