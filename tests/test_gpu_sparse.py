@@ -278,3 +278,29 @@ def test_coordmap_pyramid_refuses_what_create_refuses(gpu):
         B.CoordMap.pyramid(far, 4, 1)
     empty = B.CoordMap.pyramid(torch.zeros((0, 4), dtype=torch.int32, device=gpu), 4, 0)
     assert [m.n for m in empty] == [0, 0, 0, 0]
+
+
+def test_coordmap_pyramid_beyond_its_packed_scan_limit(gpu):
+    """2^21 rows and more do not fit the 21-bit fields of the pyramid's packed scan: cs_coordmap_pyramid then takes the
+    chained create / stride path itself and must return the same maps."""
+    from corsair_amd import backend as B
+
+    side = 130                                            # 130^3 = 2 197 000 >= 2^21
+    idx = np.arange(side ** 3, dtype=np.int64)
+    rows = np.empty((len(idx), 4), np.int32)
+    rows[:, 0] = idx % 3
+    rows[:, 1], rows[:, 2], rows[:, 3] = np.unravel_index(idx, (side, side, side))
+    rows[:, 1:] -= side // 2
+    assert len(rows) >= 1 << 21
+    g = torch.from_numpy(rows).to(gpu)
+    c1 = B.CoordMap.create(g, 1)
+    chain = [c1, c1.stride(2)]
+    chain.append(chain[-1].stride(2))
+    chain.append(chain[-1].stride(2))
+    pyr = B.CoordMap.pyramid(g, 4, 3)
+    for a, b in zip(chain, pyr):
+        assert a.n == b.n and a.tensor_stride == b.tensor_stride
+        assert torch.equal(a.coords, b.coords)
+    ka = B.KernelMap.build(chain[3], chain[2], 3, True)
+    kb = B.KernelMap.build(pyr[3], pyr[2], 3, True)
+    assert ka.num_pairs == kb.num_pairs and torch.equal(ka.table(), kb.table())
