@@ -1200,7 +1200,15 @@ __global__ __launch_bounds__(256) void k_topk_mfma(const float* __restrict__ Q, 
 }
 
 // Re-score the shortlist of one query with the canonical chain and keep the k best (dist, idx).
+// One workgroup per query, one THREAD per candidate (the f64 chain of a candidate is sequential in the feature index:
+// that order is the parity contract), 256 candidates at a time.  Round 5: the candidates' rows come through LDS in
+// chunks of TKR_CH features -- 32 consecutive lanes copy one row's 128-byte piece, so a wave's load touches two cache
+// lines, and every thread then walks ITS row in LDS (pitch TKR_CH + 1: conflict-free) -- and the ranking sorts the next
+// power of two above the candidate count.  Before, every thread read its own row from global memory (64 cache lines per
+// wave-load, 256 loads per thread) and the bitonic network always ran over TKM_MERGE_CAP = 1 024 slots: 2.97 ms per
+// 10 240 x 144 candidates of 256-d, as much as a fifth of the shortlist kernel it follows.
 constexpr int TKM_MERGE_CAP = 1024;
+constexpr int TKR_CH = 32;
 __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ Q,
                                                       const float* __restrict__ X, int d,
                                                       const int* __restrict__ cand_i, int ncand,
@@ -1208,31 +1216,58 @@ __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ 
                                                       int* carry_i) {
   __shared__ unsigned long long sd[TKM_MERGE_CAP];
   __shared__ int si[TKM_MERGE_CAP];
+  __shared__ float rows[256][TKR_CH + 1];
+  __shared__ float qs[TKR_CH];
+  __shared__ int srow[256];
   const int tid = threadIdx.x;
   const int64_t qi = blockIdx.x;
   const unsigned long long INF_BITS = 0x7ff0000000000000ULL;
-  for (int i = tid; i < TKM_MERGE_CAP; i += 256) {
-    unsigned long long dv = INF_BITS;
-    int iv = 0x7fffffff;
-    if (i < ncand) {
-      const int row = cand_i[qi * ncand + i];
+  int P = 2;
+  while (P < ncand || P < k) P <<= 1;
+  if (P > TKM_MERGE_CAP) P = TKM_MERGE_CAP;   // (the callers keep ncand <= TKM_MERGE_CAP)
+  for (int gb = 0; gb < P; gb += 256) {
+    const int i = gb + tid;
+    const int row = i < ncand ? cand_i[qi * ncand + i] : 0x7fffffff;
+    __syncthreads();   // the previous group has finished reading rows / srow
+    srow[tid] = row;
+    double acc = 0.0;
+    const int n_rows = min(256, ncand - gb);   // candidates of this group (block-uniform, may be <= 0)
+    for (int c0 = 0; c0 < d && n_rows > 0; c0 += TKR_CH) {
+      const int cl = min(TKR_CH, d - c0);
+      __syncthreads();   // srow visible; the previous chunk has been consumed
+      {
+        // thread (r0, c) copies column c of the rows r0, r0 + 8, ...: all of its loads are issued before the first one is
+        // waited for (unconditional, clamped addresses -- a load under a condition is waited for at once)
+        static_assert(TKR_CH == 32, "one 32-lane half-wave per row piece");
+        const int c = tid & 31, r0 = tid >> 5;
+        const int cc = c0 + (c < cl ? c : 0);
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int rr = srow[r0 + 8 * j];
+          v[j] = X[(int64_t)(rr != 0x7fffffff ? rr : 0) * d + cc];
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rows[r0 + 8 * j][c] = v[j];
+      }
+      if (tid < cl) qs[tid] = Q[qi * d + c0 + tid];
+      __syncthreads();
       if (row != 0x7fffffff) {
-        double acc = 0.0;
-        for (int c = 0; c < d; ++c) {
-          const double diff = (double)Q[qi * d + c] - (double)X[(int64_t)row * d + c];
+        for (int c = 0; c < cl; ++c) {
+          const double diff = (double)qs[c] - (double)rows[tid][c];
           acc = fma(diff, diff, acc);
         }
-        dv = (unsigned long long)__double_as_longlong(acc);
-        iv = row;
       }
     }
-    sd[i] = dv;
-    si[i] = iv;
+    if (i < TKM_MERGE_CAP) {
+      sd[i] = row != 0x7fffffff ? (unsigned long long)__double_as_longlong(acc) : INF_BITS;
+      si[i] = row;
+    }
   }
   __syncthreads();
-  for (int size = 2; size <= TKM_MERGE_CAP; size <<= 1) {
+  for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < TKM_MERGE_CAP / 2; t += 256) {
+      for (int t = tid; t < P / 2; t += 256) {
         const int lo = (t / stride) * stride * 2 + (t % stride);
         const int hi = lo + stride;
         const bool up = ((lo & size) == 0);
@@ -1279,6 +1314,7 @@ __global__ __launch_bounds__(256) void k_topk_rescore(const float* __restrict__ 
 constexpr int TKF_ROWS = 64;   // catalog rows per LDS stage (2 MFMA row tiles); the image is padded to whole 64s
 constexpr int TKF_QT = 256;    // queries per workgroup (8 waves x 32)
 constexpr int TKF_KK = 12;     // shortlist per lane (two lanes per query and catalog split)
+constexpr int TKF_AHEAD = 2;   // MFMA steps by which the LDS reads of the A fragments run ahead
 
 // f16 image of n rows (+ zero rows up to n_pad): per 16 features [hi(16) | lo(16)] of scale * X
 __global__ void k_tkf_pack(const float* __restrict__ X, int64_t n, int64_t n_pad, int d, float scale,
@@ -1316,13 +1352,25 @@ __global__ void k_max_bits(const double* __restrict__ v, int64_t n, unsigned* __
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));  // non-negative floats order like uints
 }
 
-// grid: x = query tile (TKF_QT), y = catalog split; 512 threads; dynamic LDS: 2 stages + 2 x TKF_ROWS floats.
+// work item = (catalog split, query tile of TKF_QT); 512 threads; dynamic LDS: 2 stages + 2 x TKF_ROWS floats.
 // cand_i: [nq][nsplit * 2][TKF_KK], tau: [nq][nsplit * 2]
 template <int DCH, int TERMS, int ROWS>
 __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ qimg, int64_t nq,
                                                   const _Float16* __restrict__ ximg, int64_t nx,
-                                                  const double* __restrict__ xn, int nsplit,
+                                                  const double* __restrict__ xn, int nsplit, int qtiles, int xcd_deal,
                                                   int* __restrict__ cand_i, float* __restrict__ tau) {
+  // 1-D grid of 8 * ceil(qtiles * nsplit / 8) workgroups.  The hardware deals workgroup b to XCD b % 8: the work items
+  // (catalog split, query tile) -- query tile fastest -- are cut into 8 contiguous runs, one per XCD, so that the
+  // workgroups that share an XCD's 4-MiB L2 stream the SAME catalog split at about the same pace (each split's image
+  // is then read from HBM / Infinity Cache about once per XCD that works on it instead of once per workgroup: at
+  // 10 240 x 10^6 x 256-d, 40 query tiles x 6 splits, a workgroup needs 10.6 B per cycle at the full matrix rate, 6 TB/s
+  // over the chip).  xcd_deal = 0 (CS_TOPK_XCD=0): item = workgroup id, the mapping of rounds 2-4.
+  const int n_items = qtiles * nsplit;
+  const int per_xcd = (n_items + 7) / 8;
+  const int item = xcd_deal ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (item >= n_items) return;
+  const int split = item / qtiles;
+  const int qtile = item - split * qtiles;
   constexpr int PITCH_B = DCH * 64 + 16;              // bytes per image row
   constexpr int STAGE_BYTES = ROWS * PITCH_B;         // whole KiB for DCH = 4, 8, 16; 64.5 KiB for DCH = 32
   constexpr int STAGE_PIECES = (STAGE_BYTES + 1023) / 1024;   // 1-KiB LDS-DMA instructions (the last may be partial)
@@ -1336,9 +1384,9 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
   const int col = lane & 31;
-  const int64_t my_q = (int64_t)blockIdx.x * TKF_QT + wave * 32 + col;
+  const int64_t my_q = (int64_t)qtile * TKF_QT + wave * 32 + col;
   const int64_t per = ((nx + nsplit - 1) / nsplit + TKF_ROWS - 1) / TKF_ROWS * TKF_ROWS;
-  const int64_t xb = (int64_t)blockIdx.y * per;
+  const int64_t xb = (int64_t)split * per;
   const int64_t xe = min(nx, xb + per);
   // B operands of the wave's 32 queries: lane supplies k = 8 half .. +8 of every 16-feature chunk
   f16x8 qh[DCH], ql[TERMS == 3 ? DCH : 1];
@@ -1404,37 +1452,55 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
       }
     }
     const char* st = lds + buf * STAGE_PITCH + col * PITCH_B + half * 16;
+    // The A fragments of step i + TKF_AHEAD are requested BEFORE the MFMAs of step i are issued (a ring of register
+    // pairs): left to itself hipcc asks for a step's two ds_read_b128 right in front of its MFMAs and waits for them
+    // at once -- the whole LDS latency once per 3 MFMAs, with two waves per SIMD the matrix pipe sat at 0.37.
+    constexpr int NSTEP = DCH * NT;
+    f16x8 rah[TKF_AHEAD + 1], ral[TKF_AHEAD + 1];
+    auto fetch = [&](int i) {
+      const int c = i / NT, t = i % NT;
+      rah[i % (TKF_AHEAD + 1)] = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64);
+      ral[i % (TKF_AHEAD + 1)] = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64 + 32);
+    };
 #pragma unroll
-    for (int c = 0; c < DCH; ++c) {
+    for (int i = 0; i < TKF_AHEAD; ++i) fetch(i);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(st + t * 32 * PITCH_B + c * 64 + 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc[t], 0, 0, 0);
-        if (TERMS == 3) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc[t], 0, 0, 0);
-      }
+    for (int i = 0; i < NSTEP; ++i) {
+      if (i + TKF_AHEAD < NSTEP) fetch(i + TKF_AHEAD);
+      __builtin_amdgcn_sched_barrier(0);   // keep the request in front of this step's MFMAs
+      const int c = i / NT, t = i % NT;
+      const f16x8 ah = rah[i % (TKF_AHEAD + 1)], al = ral[i % (TKF_AHEAD + 1)];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc[t], 0, 0, 0);
+      if (TERMS == 3) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // One test per 32 x 32 tile (v_min3 tree over the lane's 16 results against its KK-th best) instead of one per result:
+    // late in the scan a wave finds a candidate in about one tile of four.  The insertion itself is branch-free
+    // (one v_med3 per slot for the sorted values, two selects for the rows): written as the usual compare-and-carry loop
+    // hipcc copied the whole list at every slot, ~1 000 cycles per event with 2.6 events per wave and stage -- together
+    // with the 32 compare-and-branch sequences more than the stage's MFMAs.
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      float m = acc[t][0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[t][r];
-        if (v < bd[TKF_KK - 1]) {
-          float cd = v;
-          int ci = (int)(base + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-          bool carry = false;
+      for (int r = 1; r < 16; ++r) m = fminf(m, acc[t][r]);
+      if (m < bd[TKF_KK - 1]) {
 #pragma unroll
-          for (int s2 = 0; s2 < TKF_KK; ++s2) {
-            if (carry || cd < bd[s2]) {
-              carry = true;
-              const float td = bd[s2];
-              const int ti = bi[s2];
-              bd[s2] = cd;
-              bi[s2] = ci;
-              cd = td;
-              ci = ti;
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r];
+          if (v < bd[TKF_KK - 1]) {
+            const int ci = (int)(base + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            bool lt_cur = true;   // v < bd[KK - 1]
+#pragma unroll
+            for (int j = TKF_KK - 1; j >= 1; --j) {
+              const bool lt_prev = v < bd[j - 1];
+              bi[j] = lt_prev ? bi[j - 1] : (lt_cur ? ci : bi[j]);
+              bd[j] = __builtin_amdgcn_fmed3f(bd[j - 1], v, bd[j]);
+              lt_cur = lt_prev;
             }
+            bi[0] = lt_cur ? ci : bi[0];
+            bd[0] = fminf(bd[0], v);
           }
         }
       }
@@ -1443,7 +1509,7 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
     buf ^= 1;
   }
   if (my_q < nq) {
-    const int64_t slot = my_q * (nsplit * 2) + blockIdx.y * 2 + half;
+    const int64_t slot = my_q * (nsplit * 2) + split * 2 + half;
 #pragma unroll
     for (int j = 0; j < TKF_KK; ++j) cand_i[slot * TKF_KK + j] = bi[j];
     tau[slot] = bd[TKF_KK - 1];
@@ -1451,14 +1517,18 @@ __global__ __launch_bounds__(512) void k_topk_f16(const _Float16* __restrict__ q
 }
 
 template <int DCH, int TERMS, int ROWS>
-static int launch_topk_f16(dim3 grid, hipStream_t s, const _Float16* qimg, int64_t nq, const _Float16* ximg,
+static int launch_topk_f16(int qtiles, hipStream_t s, const _Float16* qimg, int64_t nq, const _Float16* ximg,
                            int64_t nx, const double* xn, int nsplit, int* cand_i, float* tau) {
   constexpr int LDS_BYTES = 2 * ((ROWS * (DCH * 64 + 16) + 1023) / 1024 * 1024) + 2 * ROWS * (int)sizeof(float);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_f16<DCH, TERMS, ROWS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   CS_REQUIRE(attr == hipSuccess, CS_ERR_HIP, "cs_l2_topk: cannot reserve %d bytes of LDS", LDS_BYTES);
+  const char* e = getenv("CS_TOPK_XCD");
+  const int xcd_deal = !(e && e[0] == '0');
+  const int n_items = qtiles * nsplit;
+  const dim3 grid((unsigned)(xcd_deal ? 8 * ((n_items + 7) / 8) : n_items));
   hipLaunchKernelGGL((k_topk_f16<DCH, TERMS, ROWS>), grid, dim3(512), LDS_BYTES, s, qimg, nq, ximg, nx, xn, nsplit,
-                     cand_i, tau);
+                     qtiles, xcd_deal, cand_i, tau);
   return CS_OK;
 }
 
@@ -2229,7 +2299,7 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   // query to the exact re-score: 10 240 x 10^6 x 256-d went from 30 to 22.5 ms with 6 splits instead of 13);
   // the smaller images fit two per CU
   const int wg_slots = getenv("CS_TOPK_SLOTS") ? atoi(getenv("CS_TOPK_SLOTS")) : (d >= 256 ? 256 : 512);
-  int nsplit = d >= 256 ? (int)(wg_slots / qtiles) : (int)ceil_div(wg_slots, qtiles);
+  int nsplit = (int)(wg_slots / qtiles);   // (rounded DOWN: one workgroup more than slots costs a whole second round)
   if (nsplit < 2) nsplit = 2;   // (10^6 x 10^6: two half-catalog rounds measured 8 % faster than one full one)
   if (nsplit > 32) nsplit = 32;
   while (nsplit > 1 && nx / nsplit < 8 * TKF_ROWS) --nsplit;
@@ -2264,12 +2334,11 @@ static int topk_f16_shortlist(const float* d_q, int64_t nq, const float* d_x, in
   hipLaunchKernelGGL(k_row_norms, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, d_q, nq, d, qn.p);
   hipLaunchKernelGGL(k_tkf_pack, dim3((unsigned)ceil_div(nq * dch, 256)), dim3(256), 0, s, d_q, nq, nq, d,
                      -2.0f, qimg.p, dch * 32);
-  const dim3 grid((unsigned)qtiles, (unsigned)nsplit);
   const int terms = dch == 32 ? 2 : 3;
-  int rc = dch == 32   ? launch_topk_f16<32, 2, 32>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
-           : dch == 16 ? launch_topk_f16<16, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
-           : dch == 8  ? launch_topk_f16<8, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
-                       : launch_topk_f16<4, 3, 64>(grid, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p);
+  int rc = dch == 32   ? launch_topk_f16<32, 2, 32>((int)qtiles, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+           : dch == 16 ? launch_topk_f16<16, 3, 64>((int)qtiles, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+           : dch == 8  ? launch_topk_f16<8, 3, 64>((int)qtiles, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p)
+                       : launch_topk_f16<4, 3, 64>((int)qtiles, s, qimg.p, nq, cat.ximg, nx, cat.xn, nsplit, cand_i.p, tau.p);
   if (rc) return rc;
   hipLaunchKernelGGL(k_topk_rescore, dim3((unsigned)nq), dim3(256), 0, s, d_q, d_x, d, cand_i.p, ncand, k,
                      cd.p, ci.p);
