@@ -576,10 +576,17 @@ constexpr int PF_STAT = 17;     // per-problem statistics of the pair image: sma
 constexpr float PF_SMAX = 128.0f;       // point norm above which a problem bypasses the prefilter
                                         // (f16 range: |s|^2 + |q|^2 and q (x) s must stay below 65504)
 
+// f64 -> f16 through f32 (v_cvt_f32_f64 + v_cvt_f16_f32).  gfx950 has no direct conversion: `(_Float16)double` is a
+// ~25-instruction integer sequence, and the prefilter's operand kernels make 16 - 32 of them per hypothesis and per pair (a sixth
+// of k_ransac_hyp's instructions).  The two roundings can differ from the single one by one f16 ulp in rare ties; nothing
+// below assumes a correctly rounded value -- every bound is computed from the value this function RETURNS (|x - f16_of(x)|),
+// and its relative error 2^-11 + 2^-24 sits inside the constants' slack (2.002 for 2 sqrt(1.001), 1.0005).
+__device__ __forceinline__ _Float16 f16_of(double v) { return (_Float16)(float)v; }
+
 __device__ __forceinline__ void split16(double v, _Float16* hi, _Float16* lo) {
-  const _Float16 h = (_Float16)v;
+  const _Float16 h = f16_of(v);
   *hi = h;
-  *lo = (_Float16)(v - (double)h);
+  *lo = f16_of(v - (double)h);
 }
 
 // rows of problem p in the f16 pair image: m rounded up to whole LDS stages
@@ -617,15 +624,17 @@ __global__ __launch_bounds__(256) void k_ransac_pair_sums(const RansacProb* __re
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = a[c];
   }
   __syncthreads();
-  if (threadIdx.x < 6) sums[blockIdx.x * 6 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  // what is stored is the MEAN (the six f64 divisions were made by every hypothesis and every pair row that read the sums)
+  if (threadIdx.x < 6) {
+    const double sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const double v = sum / (double)(pr.m > 0 ? pr.m : 1);
+    sums[blockIdx.x * 6 + threadIdx.x] = (v == v && fabs(v) < 1.0e30) ? v : 0.0;   // non-finite input: no centring (the rows are rejected by their norm)
+  }
 }
 __device__ __forceinline__ void pf_centre(const double* __restrict__ sums, int p, int m, double (&mu)[6]) {
-  const double dm = (double)(m > 0 ? m : 1);
+  (void)m;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    const double v = sums[p * 6 + c] / dm;
-    mu[c] = (v == v && fabs(v) < 1.0e30) ? v : 0.0;   // non-finite input: no centring (the rows are rejected by their norm)
-  }
+  for (int c = 0; c < 6; ++c) mu[c] = sums[p * 6 + c];
 }
 
 // NM = 2: rows [bh | bl | pad] of the K = 32 form.  NM = 1 (round 4): rows [bh | pad] of the K = 16 form -- the matrix pipe
@@ -741,13 +750,13 @@ __global__ __launch_bounds__(256) void k_ransac_pack16_b0(const RansacProb* __re
     double e_t = 0.0, e_rot = 0.0;
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
-      const double lo = fabs(b[k] - (double)(_Float16)b[k]);
+      const double lo = fabs(b[k] - (double)f16_of(b[k]));
       if (k >= 4 && k <= 12) e_rot += lo; else e_t += lo;
     }
     const double ep = (1.0 + 0x1p-10) * (a_rot * e_rot + a_t * e_t);
     // round toward -inf into f16: RNE first, one ulp down when that landed above
     const double v = (b[0] - beta) - ep - 0x1p-40 * (fabs(b[0]) + beta + ep);   // (the f64 roundings of the terms themselves)
-    _Float16 h = (_Float16)v;
+    _Float16 h = f16_of(v);
     if ((double)h > v) {
       unsigned short u = __builtin_bit_cast(unsigned short, h);
       // next representable value below: magnitude down for positive values, up for negative ones (+0 -> -min subnormal)
@@ -824,7 +833,7 @@ __device__ __forceinline__ void pf_emit_row(const RansacProb& pr, int p, int h, 
   double drop = 0.0;  // sum_k |a_k - a_hi_k| max |b_k|
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const _Float16 hi = usable ? (_Float16)a[k] : (_Float16)0.0f;
+    const _Float16 hi = usable ? f16_of(a[k]) : (_Float16)0.0f;
     row.h[k] = hi;
     if (usable) drop += fabs(a[k] - (double)hi) * (double)__uint_as_float(stat[p * PF_STAT + 1 + k]);
   }
