@@ -146,8 +146,11 @@ struct PyrArgs {
   int32_t* counts;                                  // rows of level l (l >= 1)
 };
 
+// (the pyramid kernels are only launched for power-of-two cells -- cs_coordmap_pyramid takes the chained path otherwise --:
+// a mask, without the division arm of floor_to_cell and the uniform branch around it)
+__device__ __forceinline__ int floor_to_cell2(int a, int cell) { return a & ~(cell - 1); }
 __device__ __forceinline__ uint64_t pyr_key(int b, int x, int y, int z, int cell) {
-  return pack_key(b, floor_to_cell(x, cell), floor_to_cell(y, cell), floor_to_cell(z, cell));
+  return pack_key(b, floor_to_cell2(x, cell), floor_to_cell2(y, cell), floor_to_cell2(z, cell));
 }
 
 __global__ __launch_bounds__(256) void k_pyr_insert(const int32_t* __restrict__ coords, int64_t n, const PyrArgs a) {
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void k_pyr_insert(const int32_t* __restrict__ 
     if (l < a.n_levels) {
       const int cell = a.lv[l].cell;
       // (a floor cell can fall on -32768 when the coordinate itself is in range: refused like cs_coordmap_stride does)
-      if (l > 0 && !coord_in_range(c.x, floor_to_cell(c.y, cell), floor_to_cell(c.z, cell), floor_to_cell(c.w, cell)))
+      if (l > 0 && !coord_in_range(c.x, floor_to_cell2(c.y, cell), floor_to_cell2(c.z, cell), floor_to_cell2(c.w, cell)))
         atomicOr(&a.status[0], 1);
       key[l] = pyr_key(c.x, c.y, c.z, c.w, cell);
       slot[l] = hash64(key[l]) & a.lv[l].mask;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void k_pyr_emit(const int32_t* __restrict__ co
   for (int l = 1; l < PYR_MAX_LEVELS; ++l)
     if (l < a.n_levels && ((f >> (PYR_FIELD * (l - 1))) & 1ULL)) {
       const int cell = a.lv[l].cell;
-      const int x = floor_to_cell(c.y, cell), y = floor_to_cell(c.z, cell), z = floor_to_cell(c.w, cell);
+      const int x = floor_to_cell2(c.y, cell), y = floor_to_cell2(c.z, cell), z = floor_to_cell2(c.w, cell);
       const int32_t o = (int32_t)((p >> (PYR_FIELD * (l - 1))) & ((1ULL << PYR_FIELD) - 1));
       reinterpret_cast<int4*>(a.lv[l].coords)[o] = make_int4(c.x, x, y, z);
       const uint64_t key = pack_key(c.x, x, y, z);
@@ -628,12 +631,15 @@ __global__ __launch_bounds__(NT) void k_level_maps(const LevelArgs a) {
   if (!any) return;
   unsigned long long* tr = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+  // cells are counted in units of the tensor stride, a power of two for every level the network makes: shifts and masks.
+  // (A stride that is not one goes through the global table below.  With the general `v / unit` kept as the other arm of a
+  // select, every probe carried six uniform branches around six 30-instruction integer divisions.)
   const int ushift = a.ushift, unit = a.unit;
-  auto udiv = [&](int v) { return ushift >= 0 ? v >> ushift : v / unit; };          // v >= 0
-  auto umult = [&](int v) { return ushift >= 0 ? (v & (unit - 1)) == 0 : v % unit == 0; };
+  auto udiv = [&](int v) { return v >> ushift; };                    // v >= 0
+  auto umult = [&](int v) { return (v & (unit - 1)) == 0; };
   auto bucket_of = [&](uint32_t key) { return __umulhi(key * 2654435761u, (uint32_t)NB); };   // [0, NB)
 
-  bool use_lds = n_in <= MAX_ROWS;                   // workgroup-uniform
+  bool use_lds = n_in <= MAX_ROWS && ushift >= 0;    // workgroup-uniform
   int4 c[RPT];
   if (use_lds) {
 #pragma unroll
@@ -1008,7 +1014,8 @@ int cs_coordmap_pyramid(const int32_t* d_coords, int64_t n, int tensor_stride, i
   CS_REQUIRE(n == 0 || d_coords, CS_ERR_INVALID, "cs_coordmap_pyramid: coords is NULL");
   CS_REQUIRE(tensor_stride >= 1, CS_ERR_INVALID, "cs_coordmap_pyramid: bad tensor stride");
   static const bool chained = getenv("CS_PYRAMID") && getenv("CS_PYRAMID")[0] == '0';
-  if (n == 0 || n >= (1LL << PYR_FIELD) || chained) {
+  const bool pow2 = (tensor_stride & (tensor_stride - 1)) == 0;   // cells of every level are tensor_stride << l
+  if (n == 0 || n >= (1LL << PYR_FIELD) || chained || !pow2) {
     int rc = cs_coordmap_create(d_coords, n, tensor_stride, stream, &out[0]);
     for (int l = 1; l < n_levels && rc == CS_OK; ++l) rc = cs_coordmap_stride(out[l - 1], 2, stream, &out[l]);
     if (rc != CS_OK)
