@@ -577,73 +577,92 @@ __global__ __launch_bounds__(256) void k_symcut_finish(
   const double (*km_centers)[12] = reinterpret_cast<const double (*)[12]>(km_centers_g + (int64_t)blk * n_init * 12);
   const double* km_inertia = km_inertia_g + (int64_t)blk * n_init;
   // ---- 4. best restart + gate statistics -----------------------------------------------------
-  if (tid == 0) {
-    // the first restart, then any with a smaller inertia AND a different clustering (sklearn
-    // _is_same_clustering: the one-directional label mapping must be consistent)
-    int best = 0;
+  // Wave 0, one lane per restart / per selected point (n_init <= 10, n_sel <= 64).  Round 5: this section was ONE thread
+  // walking the restarts' label words and the selected points with a global load (and its latency) per step while the
+  // other 255 waited -- most of the kernel's 208 us per chair step.  The arithmetic is unchanged: what was a sequential
+  // f64 sum (the per-cluster mean distance) is still summed by one lane in point order, from LDS.
+  __shared__ double s_dist[SYM_MAX_NN];
+  __shared__ int s_b[SYM_MAX_NN];
+  KmState st;   // centres of the chosen restart (wave 0)
+  if (tid < 64) {
     const unsigned long long* km_lab = km_labels_g + (int64_t)blk * n_init * 2;
+    const bool has_r = tid < n_init;
+    const double my_in = has_r ? km_inertia[tid] : 0.0;
+    const unsigned long long my_lo = has_r ? km_lab[2 * tid] : 0ULL, my_hi = has_r ? km_lab[2 * tid + 1] : 0ULL;
+    const bool act = tid < n_sel;
+    const int sh = 2 * (tid & 31);
+    // the first restart, then any with a smaller inertia AND a different clustering (sklearn _is_same_clustering: the
+    // one-directional label mapping must be consistent, i.e. the points of one label of r carry ONE label of best)
+    int best = 0;
     for (int r = 1; r < n_init; ++r) {
-      if (!(km_inertia[r] < km_inertia[best])) continue;
-      int mapping[4] = {-1, -1, -1, -1};
+      if (!(__shfl(my_in, r) < __shfl(my_in, best))) continue;   // (wave-uniform)
+      // (every shuffle with all 64 lanes active: a source lane that sits out of a divergent arm returns nothing)
+      const unsigned long long r_lo = __shfl(my_lo, r), r_hi = __shfl(my_hi, r);
+      const unsigned long long b_lo = __shfl(my_lo, best), b_hi = __shfl(my_hi, best);
+      const unsigned long long rw = tid < 32 ? r_lo : r_hi;
+      const unsigned long long bw = tid < 32 ? b_lo : b_hi;
+      const int la = (int)((rw >> sh) & 3ULL), lb = (int)((bw >> sh) & 3ULL);
       bool same_clu = true;
-      for (int i = 0; i < n_sel && same_clu; ++i) {
-        const int a = (int)((i < 32 ? km_lab[2 * r] >> (2 * i) : km_lab[2 * r + 1] >> (2 * (i - 32))) & 3ULL);
-        const int b = (int)((i < 32 ? km_lab[2 * best] >> (2 * i) : km_lab[2 * best + 1] >> (2 * (i - 32))) & 3ULL);
-        int m = mapping[0];
 #pragma unroll
-        for (int c = 1; c < 4; ++c) m = a == c ? mapping[c] : m;
-        if (m == -1) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (a == c) mapping[c] = b;
-        } else if (m != b) {
-          same_clu = false;
-        }
+      for (int c = 0; c < 4; ++c) {
+        const unsigned long long mk = __ballot(act && la == c);
+        const int lb_first = __shfl(lb, mk ? __ffsll((long long)mk) - 1 : 0);
+        if (__ballot(act && la == c && lb != lb_first)) same_clu = false;
       }
       if (!same_clu) best = r;
     }
-    KmState st;
+    if (tid < 12) {
+      const double v = tid < 3 * K ? km_centers[best][tid] : 0.0;
+      sel_centers[tid] = v;
+      oc[tid] = v;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       st.cx[c] = km_centers[best][3 * c + 0];
       st.cy[c] = km_centers[best][3 * c + 1];
       st.cz[c] = km_centers[best][3 * c + 2];
     }
-    for (int c = 0; c < 12; ++c) {
-      sel_centers[c] = c < 3 * K ? km_centers[best][c] : 0.0;
-      oc[c] = sel_centers[c];
-    }
-    double min_cd = INFINITY;
-    for (int c = 0; c < K; ++c)
-      for (int d = c + 1; d < K; ++d) {
-        const double dd = sqrt(dist2_3(km_centers[best][3 * c], km_centers[best][3 * c + 1],
-                                       km_centers[best][3 * c + 2], km_centers[best][3 * d],
-                                       km_centers[best][3 * d + 1], km_centers[best][3 * d + 2]));
-        if (dd < min_cd) min_cd = dd;
-      }
-    double esum[4] = {0, 0, 0, 0};
-    int ecnt[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n_sel; ++i) {
+    if (act) {
       double dm;
-      const int b = nearest_center(st, K, pts[i][0], pts[i][1], pts[i][2], &dm);
-      const double dist = sqrt(dm);
+      s_b[tid] = nearest_center(st, K, pts[tid][0], pts[tid][1], pts[tid][2], &dm);
+      s_dist[tid] = sqrt(dm);
+    }
+  }
+  __syncthreads();
+  {
+    if (tid == 0) {
+      double min_cd = INFINITY;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (b == c) {
-          esum[c] += dist;
-          ecnt[c] += 1;
-        }
-    }
-    double max_err = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < K) {
-        const double e = ecnt[c] > 0 ? esum[c] / (double)ecnt[c] : INFINITY;
-        if (e > max_err) max_err = e;
+        for (int d = c + 1; d < 4; ++d)
+          if (d < K) {
+            const double dd = sqrt(dist2_3(st.cx[c], st.cy[c], st.cz[c], st.cx[d], st.cy[d], st.cz[d]));
+            if (dd < min_cd) min_cd = dd;
+          }
+      double esum[4] = {0, 0, 0, 0};
+      int ecnt[4] = {0, 0, 0, 0};
+      for (int i = 0; i < n_sel; ++i) {
+        const int bsel = s_b[i];
+        const double dist = s_dist[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (bsel == c) {
+            esum[c] += dist;
+            ecnt[c] += 1;
+          }
       }
+      double max_err = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < K) {
+          const double e = ecnt[c] > 0 ? esum[c] / (double)ecnt[c] : INFINITY;
+          if (e > max_err) max_err = e;
+        }
+      }
+      out_min_cdist[blk] = min_cd;
+      out_max_err[blk] = max_err;
     }
-    out_min_cdist[blk] = min_cd;
-    out_max_err[blk] = max_err;
   }
   if (tid < 4) counts[tid] = 0;
   __syncthreads();
@@ -656,13 +675,25 @@ __global__ __launch_bounds__(256) void k_symcut_finish(
       st.cz[c] = sel_centers[3 * c + 2];
     }
     int local[4] = {0, 0, 0, 0};
-    for (int i = tid; i < n; i += 256) {
-      double dm;
-      const int b = nearest_center(st, K, (double)xyz[(base + i) * 3 + 0],
-                                   (double)xyz[(base + i) * 3 + 1],
-                                   (double)xyz[(base + i) * 3 + 2], &dm);
+    // four points per thread and trip: their twelve loads are issued together (clamped addresses), not one point per
+    // memory round trip
+    for (int i0 = tid; i0 < n; i0 += 256 * 4) {
+      float p[4][3];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) local[c] += (b == c);
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const int64_t g = base + (i < n ? i : i0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[u][a] = xyz[g * 3 + a];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double dm;
+        const int b = nearest_center(st, K, (double)p[u][0], (double)p[u][1], (double)p[u][2], &dm);
+        const bool in = i0 + 256 * u < n;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) local[c] += (in && b == c);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)

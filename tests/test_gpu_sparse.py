@@ -304,3 +304,25 @@ def test_coordmap_pyramid_beyond_its_packed_scan_limit(gpu):
     ka = B.KernelMap.build(chain[3], chain[2], 3, True)
     kb = B.KernelMap.build(pyr[3], pyr[2], 3, True)
     assert ka.num_pairs == kb.num_pairs and torch.equal(ka.table(), kb.table())
+
+
+def test_maps_of_a_tensor_stride_that_is_not_a_power_of_two(gpu):
+    """The LDS level kernel and the pyramid kernels count cells with shifts and masks; a tensor stride of 3 must take the
+    global-table / chained paths and still give the oracle's maps (coordinates that are multiples of 3, strided to 6)."""
+    from corsair_amd import backend as B
+    from oracle import sparse as osp
+
+    coords, _, _, _ = make_batch([31, 32, 33], n_points=4000)
+    c3 = coords.copy()
+    c3[:, 1:] *= 3                                            # a stride-3 tensor's coordinates
+    g = torch.from_numpy(c3).to(gpu)
+    pyr = B.CoordMap.pyramid(g, 2, 3, tensor_stride=3)
+    want6, cell = osp.coordmap_stride(c3, 3, 2)
+    assert cell == 6 and pyr[0].tensor_stride == 3 and pyr[1].tensor_stride == 6
+    assert np.array_equal(pyr[0].coords.cpu().numpy(), c3)
+    assert np.array_equal(pyr[1].coords.cpu().numpy(), want6)
+    specs = [(pyr[0], pyr[0]), (pyr[0], pyr[1]), (pyr[1], pyr[1]), (pyr[1], pyr[0], 3, True)]
+    wants = [osp.kernel_map(c3, 3, c3, 3), osp.kernel_map(c3, 3, want6, 6), osp.kernel_map(want6, 6, want6, 6),
+             osp.kernel_map(want6, 6, c3, 3, transposed=True)]
+    for km, want in zip(B.KernelMap.build_many(specs), wants):
+        assert np.array_equal(km.table().cpu().numpy(), want)
