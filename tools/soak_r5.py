@@ -3,7 +3,8 @@ inputs (all selectable per call through the environment):
   * kernel maps: cs_coordmap_pyramid + k_level_maps (LDS, bucketised) vs chained create / stride + the global-table kernel
     (CS_PYRAMID=0 is read once per process, so the chained side calls create / stride directly; CS_KMAP_GLOBAL per call);
   * Chamfer: f16 matrix-core ranking (+ fallback) vs the f64 matrix-pipe kernel (CS_CHAMFER_F16 per call) -- bit-equal;
-  * 16-d k-NN: threshold pass + shortlist vs shortlist alone (CS_KNN_TWOPASS per call), with and without labels.
+  * 16-d k-NN: threshold pass + shortlist vs shortlist alone (CS_KNN_TWOPASS per call), with and without labels;
+  * descriptor top-k: f16 shortlist + re-score through LDS vs the exact f64 slab path (CS_TOPK_MFMA=0 per call).
 python tools/soak_r5.py [n]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -116,4 +117,34 @@ for it in range(n):
         bad += 1
         print("knn: case", it, "differs")
 print("k-NN: %d random calls, %d mismatches in total" % (n, bad))
+
+# ---- descriptor top-k: f16 shortlist + LDS re-score (round 5 rewrite) vs the exact f64 slab path (CS_TOPK_MFMA=0 per call)
+st = (ctypes.c_uint64 * 2)()
+_lib.load().cs_l2_topk_stats(st, 1)
+for it in range(n):
+    d = int(rng.choice([64, 128, 256, 256, 512]))
+    nx = int(rng.choice([64, 65, 652, 830, 5000, int(rng.integers(6000, 120000))]))
+    nq = int(rng.choice([1, 31, 32, 257, int(rng.integers(2, 3000))]))
+    k = int(rng.integers(1, min(10, nx) + 1))
+    X = synth.make_descriptors(nx, d, seed=7000 + it)
+    Qd = synth.make_descriptors(nq, d, seed=8000 + it)
+    if it % 3 == 1:
+        X[: nx // 4] = X[nx // 4: 2 * (nx // 4)]                # exact duplicates: ties by row
+    if it % 3 == 2:
+        Qd[: min(nq, nx)] = X[: min(nq, nx)]                    # queries that ARE catalog rows (distance 0)
+    sc = float(rng.choice([1.0, 1.0, 0.02, 20.0]))
+    Xt, Qt = torch.from_numpy(X * sc).to(dev), torch.from_numpy(Qd * sc).to(dev)
+    cat = B.TopkCatalog(Xt) if it % 2 == 0 else Xt
+    try:
+        os.environ["CS_TOPK_MFMA"] = "16"       # (unset, the f16 path is taken from nq * nx >= 2^24 on)
+        ia, da = B.l2_topk(Qt, cat, k, True)
+        os.environ["CS_TOPK_MFMA"] = "0"
+        ib, db = B.l2_topk(Qt, Xt, k, True)
+    finally:
+        os.environ.pop("CS_TOPK_MFMA", None)
+    if not (torch.equal(ia, ib) and torch.equal(da, db)):
+        bad += 1
+        print("topk: case", it, "differs (d %d nx %d nq %d k %d)" % (d, nx, nq, k))
+_lib.load().cs_l2_topk_stats(st, 0)
+print("top-k: %d random calls, f16 shortlist queries %d, re-done by the f64 path %d, %d mismatches in total" % (n, int(st[0]), int(st[1]), bad))
 sys.exit(1 if bad else 0)
