@@ -440,7 +440,10 @@ __device__ __forceinline__ double residual2_f64(const double (&R)[12], double sx
 }
 
 // LIST: the hypotheses are the survivors of the prefilter, hlist[p][0 .. n_surv[p]) (any order).
-template <bool LIST>
+// HPW = hypotheses per workgroup: 256 (one per lane) or 64 (round 5: the FIRST chunk of a call, 64 iterations counted
+// exactly before there is a best count to prune against -- lane = hypothesis + 64 x quarter, every quarter (= wave) takes
+// every fourth staged pair and the four partial counts meet in the integer atomics the pair-range splits use anyway).
+template <bool LIST, int HPW>
 __device__ __forceinline__ void ransac_count_tile(double (*lds)[RC_CHUNK][6], const int p, const int tile,
                                                   const int split,
                                                   const RansacProb* __restrict__ probs,
@@ -452,14 +455,17 @@ __device__ __forceinline__ void ransac_count_tile(double (*lds)[RC_CHUNK][6], co
                                                   const int32_t* __restrict__ n_surv) {
   const RansacProb pr = probs[p];
   if (pr.done) return;
+  static_assert(HPW == RC_HYP || (!LIST && HPW == 64), "hypotheses per workgroup");
+  constexpr int NPART = RC_HYP / HPW;                     // lanes that share a hypothesis (pair-interleaved)
   const int nlist = LIST ? n_surv[p] : 0;
   if (LIST) {
-    if (tile * RC_HYP >= nlist) return;
+    if (tile * HPW >= nlist) return;
   } else {
-    if (it0 + tile * RC_HYP >= pr.est_k || tile * RC_HYP >= bcount) return;  // whole block beyond the bound
+    if (it0 + tile * HPW >= pr.est_k || tile * HPW >= bcount) return;  // whole block beyond the bound
   }
   const int tid = threadIdx.x;
-  const int h = tile * RC_HYP + tid;                      // hypothesis slot of this lane
+  const int part = tid / HPW;
+  const int h = tile * HPW + (tid - part * HPW);          // hypothesis slot of this lane
   const bool mine = LIST ? h < nlist : (h < bcount && it0 + h < pr.est_k);
   const int hsel = LIST ? hlist[(int64_t)p * bmax + min(h, nlist - 1)] : min(h, bmax - 1);
   double R[12];
@@ -498,12 +504,12 @@ __device__ __forceinline__ void ransac_count_tile(double (*lds)[RC_CHUNK][6], co
     const int nrow = min(RC_CHUNK, end - base);
     if (nrow == RC_CHUNK) {
 #pragma unroll 4
-      for (int j = 0; j < RC_CHUNK; ++j) {
+      for (int j = part; j < RC_CHUNK; j += NPART) {
         const double* q = lds[buf][j];
         cnt += residual2_f64(R, q[0], q[1], q[2], q[3], q[4], q[5]) < thr2 ? 1 : 0;
       }
     } else {
-      for (int j = 0; j < nrow; ++j) {
+      for (int j = part; j < nrow; j += NPART) {
         const double* q = lds[buf][j];
         cnt += residual2_f64(R, q[0], q[1], q[2], q[3], q[4], q[5]) < thr2 ? 1 : 0;
       }
@@ -512,16 +518,16 @@ __device__ __forceinline__ void ransac_count_tile(double (*lds)[RC_CHUNK][6], co
     buf ^= 1;
   }
   if (mine) {
-    if (splits == 1)
+    if (splits == 1 && NPART == 1)
       res_cnt[(int64_t)p * bmax + hsel] = cnt;
     else
-      atomicAdd(&res_cnt[(int64_t)p * bmax + hsel], cnt);
+      atomicAdd(&res_cnt[(int64_t)p * bmax + hsel], cnt);   // (res_cnt of the chunk is zero on entry)
   }
 }
 
 // grid: x = (hypothesis tile of 256) * splits + split, y = problem.  LIST: the survivor count is only
 // known on the device, so a fixed number of tile slots (gridDim.x / splits) strides over the list.
-template <bool LIST>
+template <bool LIST, int HPW = RC_HYP>
 __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restrict__ probs,
                                                       const float* __restrict__ pk, int64_t total,
                                                       const double* __restrict__ hyp, int it0,
@@ -538,13 +544,13 @@ __global__ __launch_bounds__(256) void k_ransac_count(const RansacProb* __restri
     const int nlist = n_surv[p];
     const int tstride = gridDim.x / splits;
     for (int tile = tile0; tile * RC_HYP < nlist; tile += tstride) {
-      ransac_count_tile<LIST>(lds, p, tile, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
-                              res_cnt, hlist, n_surv);
+      ransac_count_tile<LIST, HPW>(lds, p, tile, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
+                                   res_cnt, hlist, n_surv);
       __syncthreads();  // the next tile restages LDS
     }
   } else {
-    ransac_count_tile<LIST>(lds, p, tile0, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
-                            res_cnt, hlist, n_surv);
+    ransac_count_tile<LIST, HPW>(lds, p, tile0, split, probs, pk, total, hyp, it0, bcount, bmax, splits, thr2,
+                                 res_cnt, hlist, n_surv);
   }
 }
 
@@ -1725,8 +1731,11 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
   // exact kernel of round 2 the unfiltered rounds are the expensive ones: 256 instead of 512 is +2.4 % queries/s
   // (experiment knobs: clamped -- a first chunk above bmax would index the bmax-sized scratch out of range, 0 would
   // never advance the chunk loop)
-  int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 256;
-  first_chunk = ((std::min(std::max(first_chunk, 256), bmax) + 255) / 256) * 256;
+  // Round 5: 64.  The unfiltered chunk costs its hypotheses x ALL pairs in f64 (0.31 ms per 48-problem call at 256, twice per
+  // chair step); with 64 the second chunk, [64, 512), is already prefiltered -- against the best of 64 hypotheses instead of 256,
+  // which lets a few more of its hypotheses through to the exact kernels.  Results are the sequential loop's either way.
+  int first_chunk = getenv("CS_RANSAC_FIRST") ? atoi(getenv("CS_RANSAC_FIRST")) : 64;
+  first_chunk = ((std::min(std::max(first_chunk, 64), bmax) + 63) / 64) * 64;
   int pf_from = getenv("CS_RANSAC_PF_FROM") ? atoi(getenv("CS_RANSAC_PF_FROM")) : first_chunk;
   pf_from = std::max(pf_from, first_chunk);
   // per-round state in ONE block, so a round ends with one device->host copy (into pinned memory):
@@ -1873,8 +1882,9 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
     const int32_t* xcd_prob = nullptr;
     int pslots = 1;
   };
+  // chunks: [0, first) counted exactly, [first, 512) in one piece, then doubling ([512, 1024), [1024, 2048), ...) up to bmax
   auto chunk_of = [&](int it0) {
-    int b = it0 < first_chunk ? first_chunk : (it0 < bmax ? it0 : bmax);
+    int b = it0 < first_chunk ? first_chunk : it0 < 512 ? 512 - it0 : (it0 < bmax ? it0 : bmax);
     return b > max_iter - it0 ? max_iter - it0 : b;
   };
   auto enqueue_front = [&](int it0, int par, hipStream_t st) -> Front {
@@ -1994,7 +2004,8 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       side_pending = false;
     }
     bool err_known = false;  // the fixed-point errors of all candidates are already in cand_err (by hypothesis)
-    const int tiles = (b + RC_HYP - 1) / RC_HYP;
+    const int hpw = (!pf && b <= 64) ? 64 : RC_HYP;      // hypotheses per workgroup of the unfiltered exact count
+    const int tiles = (b + hpw - 1) / hpw;
     // enough workgroups for 256 CUs x several waves; the correspondence range is split when the
     // chunk is small (integer partial sums combine exactly)
     int splits = (int)(4096 / ((int64_t)n_prob * tiles > 0 ? (int64_t)n_prob * tiles : 1));
@@ -2018,13 +2029,18 @@ int cs_ransac_batch(const float* d_src, const float* d_tgt, const int64_t* h_off
       }
     }
     if (!pf) {
-      if (splits > 1)  // partial counts of the splits are combined with integer atomics
+      if (splits > 1 || hpw != RC_HYP)  // partial counts (pair-range splits, lane quarters) are combined with integer atomics
         CS_HIP_CHECK(hipMemset2DAsync(res_cnt.p, sizeof(int32_t) * bmax, 0, sizeof(int32_t) * b,
                                       n_prob, s));
       ProfScope prof("ransac_eval", s, 30.0 * eval_pairs);
-      hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
-                         dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
-                         res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
+      if (hpw == 64)
+        hipLaunchKernelGGL((k_ransac_count<false, 64>), dim3((unsigned)(tiles * splits), (unsigned)n_prob),
+                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
+                           res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
+      else
+        hipLaunchKernelGGL(k_ransac_count<false>, dim3((unsigned)(tiles * splits), (unsigned)n_prob),
+                           dim3(256), 0, s, d_probs, pk.p, tot1, hyp_r, it0, b, bmax, splits, thr2,
+                           res_cnt.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     } else {
       // SURVEY 8d unit: 30 FLOP per (hypothesis, pair) -- the work of the exact formulation the prefilter
       // stands in for (the matrix pipe executes 64 FLOP per pair: bench.py reports both)

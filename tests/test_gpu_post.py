@@ -362,6 +362,33 @@ def test_ransac_prefilter_bound_and_identity(gpu, oracle_native, monkeypatch, sc
         assert np.array_equal(exact[0][p], wT)
 
 
+@pytest.mark.parametrize("max_iter", [40, 64, 100, 600, 60000])
+def test_ransac_first_chunk_size_leaves_the_results_unchanged(gpu, monkeypatch, max_iter):
+    """Round 5: the first (unfiltered, exactly counted) chunk of a call is 64 iterations -- lane = hypothesis + 64 x quarter of
+    the pairs in k_ransac_count<false, 64> -- and the second chunk, [64, 512), is prefiltered against the best of those 64.
+    Results equal the 256- and 512-iteration first chunks of rounds 1-4 and the prefilter-free run, also when the iteration
+    budget ends inside the first or the second chunk, and with inlier ratios from none to early-exit territory."""
+    from corsair_amd import backend as B
+
+    rng = np.random.default_rng(78)
+    specs = [(int(rng.integers(40, 9000)), float(rng.choice([0.0, 0.05, 0.3, 0.8])), i) for i in range(30)]
+    probs = [_corr_problem(rng, m, f, noise=0.02, pose_id=300 + i)[:2] for m, f, i in specs]
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).tolist()
+    S = torch.from_numpy(np.concatenate([p[0] for p in probs])).to(gpu)
+    D = torch.from_numpy(np.concatenate([p[1] for p in probs])).to(gpu)
+    out = {}
+    for first in ("64", "256", "512", "exact"):
+        if first == "exact":
+            monkeypatch.delenv("CS_RANSAC_FIRST")
+            monkeypatch.setenv("CS_RANSAC_PREFILTER", "0")
+        else:
+            monkeypatch.setenv("CS_RANSAC_FIRST", first)
+        out[first] = [t.cpu().numpy() for t in B.ransac_batch(S, D, off, 0.06, 10, max_iter, 0.999, 5)]
+    for first in ("256", "512", "exact"):
+        for a, b in zip(out["64"], out[first]):
+            assert np.array_equal(a, b), (max_iter, first)
+
+
 def test_ransac_second_stage_leaves_the_trajectory_unchanged(gpu, monkeypatch):
     """Round 4: the survivors of the K = 16 prefilter go through the K = 32 bound (a compact list per problem, one small
     launch) before they are counted exactly.  With and without it (CS_RANSAC_STAGE2) the results AND the number of
